@@ -1,0 +1,63 @@
+"""ctypes binding of libmmnn_sts.so (include/mmnn_sts.h).  The product path has NO fallback: if the library is
+missing or a call fails, an exception is raised."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmnn_sts.so")
+_lib = None
+
+
+class DenseNetConfig(Structure):
+    _fields_ = [
+        ("in_channels", c_int32), ("init_features", c_int32), ("growth_rate", c_int32), ("bn_size", c_int32),
+        ("num_blocks", c_int32), ("block_config", c_int32 * 8), ("eps", c_float), ("momentum", c_float),
+        ("dropout_prob", c_float),
+    ]
+
+
+def lib():
+    """Load the shared library once (torch must be imported first so that its HIP runtime is the one bound)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64 with the SONAME the extension needs)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m mmnn_sts_amd.build` (hipcc, gfx950). "
+            "mmnn_sts_amd has no CPU / eager fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.mmnn_version.restype = c_int32
+    L.mmnn_last_error.restype = c_char_p
+    L.mmnn_densenet_plan_create.restype = c_void_p
+    L.mmnn_densenet_plan_create.argtypes = [POINTER(DenseNetConfig), c_int32, c_int32, c_int32, c_int32]
+    L.mmnn_densenet_plan_destroy.restype = None
+    L.mmnn_densenet_plan_destroy.argtypes = [c_void_p]
+    for f in ("mmnn_densenet_param_count", "mmnn_densenet_runstat_count", "mmnn_densenet_workspace_bytes"):
+        getattr(L, f).restype = c_int64
+        getattr(L, f).argtypes = [c_void_p]
+    L.mmnn_densenet_out_shape.restype = c_int32
+    L.mmnn_densenet_out_shape.argtypes = [c_void_p] + [POINTER(c_int32)] * 4
+    L.mmnn_densenet_forward.restype = c_int32
+    L.mmnn_densenet_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
+    L.mmnn_densenet_backward.restype = c_int32
+    L.mmnn_densenet_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
+    L.mmnn_densenet_ws_offset.restype = c_int64
+    L.mmnn_densenet_ws_offset.argtypes = [c_void_p, c_char_p, c_int32, c_int32]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    """C status -> Python exception (1: ValueError, otherwise RuntimeError), SURVEY 8(b) error contract."""
+    if status == 0:
+        return
+    msg = lib().mmnn_last_error().decode("utf-8", "replace")
+    if status == 1:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (status {status})")
+
+
+def last_error() -> str:
+    return lib().mmnn_last_error().decode("utf-8", "replace")

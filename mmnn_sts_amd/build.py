@@ -1,0 +1,64 @@
+"""Build libmmnn_sts.so (hand-written HIP for gfx950) in-tree with hipcc.  `python -m mmnn_sts_amd.build`.
+
+No torch.utils.cpp_extension (it hipifies), no cmake: one object per .hip file, compiled in parallel, linked into
+mmnn_sts_amd/libmmnn_sts.so.  Objects are rebuilt only when a source or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libmmnn_sts.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
+
+
+def _newest_header():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "mmnn_sts.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _newest_header()
+    jobs = []
+    objs = []
+    for src in _sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
+            lang = ["-x", "hip"] if src.endswith(".hip") else []
+            jobs.append([hipcc, *FLAGS, *lang, "-c", s, "-o", o])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    if jobs:
+        if verbose:
+            print(f"[mmnn_sts_amd.build] compiling {len(jobs)} file(s) for {ARCH}", flush=True)
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for warn in ex.map(run, jobs):
+                if warn and verbose:
+                    sys.stderr.write(warn)
+    if jobs or not os.path.exists(LIB) or force:
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+        if verbose:
+            print(f"[mmnn_sts_amd.build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,67 @@
+// extern "C" surface of libmmnn_sts.so (declared in include/mmnn_sts.h).
+#include "../../include/mmnn_sts.h"
+
+#include <new>
+
+#include "densenet.hpp"
+
+using namespace mmnn;
+
+extern "C" {
+
+int mmnn_version(void) { return 100; }
+const char* mmnn_last_error(void) { return last_error(); }
+
+void* mmnn_densenet_plan_create(const mmnn_densenet_config* cfg, int32_t n, int32_t d, int32_t h, int32_t w) {
+  if (!cfg) { set_error("plan_create: null config"); return nullptr; }
+  if (cfg->num_blocks < 1 || cfg->num_blocks > MAX_BLOCKS) { set_error("plan_create: num_blocks %d out of range", cfg->num_blocks); return nullptr; }
+  NetCfg c;
+  c.in_channels = cfg->in_channels; c.init_features = cfg->init_features; c.growth = cfg->growth_rate; c.bn_size = cfg->bn_size;
+  c.nblocks = cfg->num_blocks;
+  for (int i = 0; i < MAX_BLOCKS; ++i) c.block_layers[i] = i < cfg->num_blocks ? cfg->block_config[i] : 0;
+  c.eps = cfg->eps; c.momentum = cfg->momentum; c.dropout_p = cfg->dropout_prob;
+  Plan* p = new (std::nothrow) Plan();
+  if (!p) { set_error("plan_create: out of host memory"); return nullptr; }
+  if (plan_build(*p, c, n, d, h, w) != 0) { delete p; return nullptr; }
+  return p;
+}
+
+void mmnn_densenet_plan_destroy(void* plan) {
+  if (!plan) return;
+  Plan* p = static_cast<Plan*>(plan);
+  plan_free(*p);
+  delete p;
+}
+
+int64_t mmnn_densenet_param_count(const void* plan) { return plan ? static_cast<const Plan*>(plan)->n_params : -1; }
+int64_t mmnn_densenet_runstat_count(const void* plan) { return plan ? static_cast<const Plan*>(plan)->n_runstats : -1; }
+int64_t mmnn_densenet_workspace_bytes(const void* plan) { return plan ? (int64_t) static_cast<const Plan*>(plan)->ws_bytes : -1; }
+
+int mmnn_densenet_out_shape(const void* plan, int32_t* c, int32_t* d, int32_t* h, int32_t* w) {
+  MMNN_REQUIRE(plan && c && d && h && w, "out_shape: null argument");
+  const Plan* p = static_cast<const Plan*>(plan);
+  const int b = p->cfg.nblocks - 1;
+  *c = p->ctot_b[b]; *d = p->Db[b]; *h = p->Hb[b]; *w = p->Wb[b];
+  return 0;
+}
+
+int mmnn_densenet_forward(void* plan, const float* params, float* runstats, const float* x, void* workspace, float* out,
+                          int32_t training, uint64_t seed, void* stream) {
+  MMNN_REQUIRE(plan, "forward: null plan");
+  return plan_forward(*static_cast<Plan*>(plan), params, runstats, x, static_cast<char*>(workspace), out, training, seed,
+                      static_cast<hipStream_t>(stream));
+}
+
+int mmnn_densenet_backward(void* plan, const float* params, const float* x, void* workspace, const float* grad_out,
+                           float* grad_params, int32_t accumulate, uint64_t seed, void* stream) {
+  MMNN_REQUIRE(plan, "backward: null plan");
+  return plan_backward(*static_cast<Plan*>(plan), params, x, static_cast<char*>(workspace), grad_out, grad_params, accumulate, seed,
+                       static_cast<hipStream_t>(stream));
+}
+
+int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j) {
+  if (!plan || !name) return -1;
+  return plan_ws_offset(*static_cast<const Plan*>(plan), name, i, j);
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// Shared device/host helpers for the MI355X (gfx950) kernels of the MMNN_STS fusion path.
+//
+// Conventions used by every kernel in this directory:
+//  * activations are fp32, channel-major per sample:  buf[n][c][v],  v = (d*H + h)*W + w  (NCDHW as the reference's
+//    collate produces it, utils/utils.py:112-117).  A dense block's concat (models/densenet.py:87-89) is ONE
+//    pre-allocated buffer; every layer writes its growth_rate channels into its slice ("in_coff/out_coff").
+//  * batch-norm statistics are accumulated by the PRODUCER of a tensor (epilogue) as fp64 sums in NREP replicas
+//    (replica = blockIdx & 7, i.e. blocks that share an XCD share a replica) and turned into per-channel affine
+//    coefficients by the CONSUMER's prologue.  fp64 atomics make the result independent of arrival order at fp32
+//    resolution.
+//  * wave = 64 lanes; MFMA = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmnn {
+
+constexpr int NREP = 8;   // replicas of each atomically accumulated statistic
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- host-side error channel (C-ABI: int status + thread-local message) -------------------------------------------
+void set_error(const char* fmt, ...);
+const char* last_error();
+#define MMNN_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::mmnn::set_error(__VA_ARGS__);           \
+      return 1;                                 \
+    }                                           \
+  } while (0)
+#define MMNN_HIP(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::mmnn::set_error("HIP error %d (%s) at %s:%d", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 2;                                                                               \
+    }                                                                                         \
+  } while (0)
+
+// ---- descriptors ----------------------------------------------------------------------------------------------------
+// Statistics of a tensor's channels: sum[r*stride + off + c], sq[...] for replica r.
+struct StatPtr {
+  double* sum;
+  double* sq;
+  int stride;   // channels per replica row
+  int off;      // first channel of the tensor inside the row
+};
+
+// Forward batch-norm of channel c:  y = a_c*x + b_c  (then ReLU where the layer has one).
+// training: batch statistics (biased variance) from `st`;  eval: running statistics.
+struct BnFwd {
+  StatPtr st;
+  const float* rmean;
+  const float* rvar;
+  const float* gamma;
+  const float* beta;
+  double inv_count;   // 1 / (N*V)
+  float eps;
+  int training;
+};
+
+// Backward through the normalisation of a tensor X with batch statistics `st`, given per-voxel upstream G and the
+// per-channel sums S1 = sum(G), S2 = sum(G*xhat):   dX = gamma_c * rstd * (G - S1/n - xhat*S2/n) = p*G + q*X + r.
+// `gamma` may be null (G already carries the consumers' gammas: dense-block concat channels).
+struct BnBwd {
+  StatPtr st;        // statistics of X
+  StatPtr s;         // s.sum = S1 replicas, s.sq = S2 replicas
+  const float* gamma;
+  double inv_count;
+  float eps;
+};
+
+// Channel dropout (nn.Dropout3d semantics, models/densenet.py:84-85): scale of channel c of sample n in layer `layer`.
+struct DropCfg {
+  uint64_t seed;
+  float p;        // 0 => disabled
+  int layer;
+};
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ double stat_total(const double* base, int stride, int idx) {
+  double t = 0.0;
+#pragma unroll
+  for (int r = 0; r < NREP; ++r) t += base[(long)r * stride + idx];
+  return t;
+}
+
+__device__ __forceinline__ void bn_fwd_coef(const BnFwd& s, int c, float& a, float& b, float& mean_f, float& rstd_f) {
+  double mean, var;
+  if (s.training) {
+    mean = stat_total(s.st.sum, s.st.stride, s.st.off + c) * s.inv_count;
+    var = stat_total(s.st.sq, s.st.stride, s.st.off + c) * s.inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)s.rmean[c];
+    var = (double)s.rvar[c];
+  }
+  double rstd = 1.0 / sqrt(var + (double)s.eps);
+  double g = (double)s.gamma[c];
+  a = (float)(g * rstd);
+  b = (float)((double)s.beta[c] - mean * g * rstd);
+  mean_f = (float)mean;
+  rstd_f = (float)rstd;
+}
+
+__device__ __forceinline__ void bn_bwd_coef(const BnBwd& s, int c, float& p, float& q, float& r) {
+  double mean = stat_total(s.st.sum, s.st.stride, s.st.off + c) * s.inv_count;
+  double var = stat_total(s.st.sq, s.st.stride, s.st.off + c) * s.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  double rstd = 1.0 / sqrt(var + (double)s.eps);
+  double m1 = stat_total(s.s.sum, s.s.stride, s.s.off + c) * s.inv_count;
+  double m2 = stat_total(s.s.sq, s.s.stride, s.s.off + c) * s.inv_count;
+  double g = s.gamma ? (double)s.gamma[c] : 1.0;
+  p = (float)(g * rstd);
+  q = (float)(-g * rstd * rstd * m2);
+  r = (float)(g * rstd * rstd * m2 * mean - g * rstd * m1);
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, layer, n, c)
+__device__ __host__ __forceinline__ float drop_scale(const DropCfg& d, int n, int c) {
+  if (d.p <= 0.f) return 1.f;
+  uint64_t x = d.seed + 0x9E3779B97F4A7C15ull * (uint64_t)(((uint64_t)(uint32_t)d.layer << 40) ^ ((uint64_t)(uint32_t)n << 20) ^ (uint64_t)(uint32_t)c);
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+  return u < d.p ? 0.f : 1.f / (1.f - d.p);
+}
+
+// ---- cross-lane helpers ---------------------------------------------------------------------------------------------
+template <int XOR>
+__device__ __forceinline__ float swz_xor(float v) {   // lane ^ XOR within each 32-lane half (ds_swizzle bit mode)
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XOR << 10) | 0x1F));
+}
+
+// Sum each of 16 per-lane values over the 32 lanes of a wave half.  On return, lane L of a half holds the total of
+// register index (L >> 1) & 15 (lanes 2t and 2t+1 hold the same total).   16 + 8 + 4 + 2 + 1 = 31 exchanges.
+__device__ __forceinline__ float half_reduce16(const float v[16], int lane) {
+  float w8[8], w4[4], w2[2], w1;
+  const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float send = b4 ? v[r] : v[r + 8];
+    float keep = b4 ? v[r + 8] : v[r];
+    w8[r] = keep + swz_xor<16>(send);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float send = b3 ? w8[r] : w8[r + 4];
+    float keep = b3 ? w8[r + 4] : w8[r];
+    w4[r] = keep + swz_xor<8>(send);
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float send = b2 ? w4[r] : w4[r + 2];
+    float keep = b2 ? w4[r + 2] : w4[r];
+    w2[r] = keep + swz_xor<4>(send);
+  }
+  {
+    float send = b1 ? w2[0] : w2[1];
+    float keep = b1 ? w2[1] : w2[0];
+    w1 = keep + swz_xor<2>(send);
+  }
+  return w1 + swz_xor<1>(w1);
+}
+
+// row of the 32x32 accumulator tile held in register r by a lane of half h (C/D layout of v_mfma_f32_32x32x2_f32)
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif  // __HIPCC__
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mmnn

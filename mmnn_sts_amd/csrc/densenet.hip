@@ -1,0 +1,575 @@
+// Launch plan of the DenseNet backbone forward / backward (see densenet.hpp).
+#include "densenet.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+
+#include "fprop.hpp"
+#include "stem.hpp"
+#include "wgrad.hpp"
+
+namespace mmnn {
+
+static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+namespace {
+struct Carver {
+  size_t cur = 0;
+  size_t take(size_t bytes) {
+    size_t o = cur;
+    cur = align_up(cur + bytes);
+    return o;
+  }
+};
+}  // namespace
+
+int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
+  MMNN_REQUIRE(cfg.nblocks >= 1 && cfg.nblocks <= MAX_BLOCKS, "plan: 1..%d dense blocks supported, got %d", MAX_BLOCKS, cfg.nblocks);
+  MMNN_REQUIRE(cfg.in_channels >= 1 && cfg.in_channels <= 4, "plan: in_channels must be 1..4, got %d", cfg.in_channels);
+  MMNN_REQUIRE(cfg.init_features >= 1 && cfg.init_features <= 64, "plan: init_features must be <= 64, got %d", cfg.init_features);
+  MMNN_REQUIRE(cfg.growth >= 1 && cfg.growth <= 32, "plan: growth_rate must be <= 32, got %d", cfg.growth);
+  MMNN_REQUIRE(cfg.bn_size >= 1 && cfg.dropout_p >= 0.f && cfg.dropout_p < 1.f, "plan: bad bn_size / dropout");
+  MMNN_REQUIRE(N >= 1 && D >= 1 && H >= 1 && W >= 1, "plan: bad input extent");
+  p.cfg = cfg; p.N = N; p.D = D; p.H = H; p.W = W;
+  p.mid = cfg.bn_size * cfg.growth;
+  p.D0 = (D - 1) / 2 + 1; p.H0 = (H - 1) / 2 + 1; p.W0 = (W - 1) / 2 + 1;
+  int d = (p.D0 - 1) / 2 + 1, h = (p.H0 - 1) / 2 + 1, w = (p.W0 - 1) / 2 + 1;
+  int c = cfg.init_features;
+  for (int b = 0; b < cfg.nblocks; ++b) {
+    MMNN_REQUIRE(cfg.block_layers[b] >= 1, "plan: empty dense block %d", b);
+    MMNN_REQUIRE(d >= 1 && h >= 1 && w >= 1, "plan: input too small, block %d has no voxels", b + 1);
+    p.Db[b] = d; p.Hb[b] = h; p.Wb[b] = w; p.Vb[b] = d * h * w;
+    p.cin_b[b] = c;
+    p.ctot_b[b] = c + cfg.block_layers[b] * cfg.growth;
+    c = p.ctot_b[b];
+    if (b != cfg.nblocks - 1) {
+      MMNN_REQUIRE(c % 2 == 0, "plan: transition halves an odd channel count");
+      c /= 2; d /= 2; h /= 2; w /= 2;
+    }
+  }
+  // ---- parameter layout (PyTorch named_parameters order of `backbone`) ----
+  long po = 0, ro = 0;
+  int nbn = 0;
+  auto bn = [&](int ch, long& w_, long& b_, long& m_, long& v_) { w_ = po; po += ch; b_ = po; po += ch; m_ = ro; ro += ch; v_ = ro; ro += ch; ++nbn; };
+  p.p_conv0 = po; po += (long)cfg.init_features * cfg.in_channels * 343;
+  bn(cfg.init_features, p.p_n0w, p.p_n0b, p.r_n0m, p.r_n0v);
+  p.layers.assign(cfg.nblocks, {});
+  p.trans.clear();
+  for (int b = 0; b < cfg.nblocks; ++b) {
+    int ci = p.cin_b[b];
+    for (int l = 0; l < cfg.block_layers[b]; ++l) {
+      LayerOff lo;
+      lo.cin = ci;
+      bn(ci, lo.n1w, lo.n1b, lo.r1m, lo.r1v);
+      lo.c1 = po; po += (long)p.mid * ci;
+      bn(p.mid, lo.n2w, lo.n2b, lo.r2m, lo.r2v);
+      lo.c2 = po; po += (long)cfg.growth * p.mid * 27;
+      p.layers[b].push_back(lo);
+      ci += cfg.growth;
+    }
+    if (b != cfg.nblocks - 1) {
+      TransOff t;
+      t.cin = ci; t.cout = ci / 2;
+      bn(ci, t.nw, t.nb, t.rm, t.rv);
+      t.cw = po; po += (long)t.cout * ci;
+      p.trans.push_back(t);
+    } else {
+      bn(ci, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v);
+    }
+  }
+  p.n_params = po; p.n_runstats = ro; p.n_bn = nbn;
+
+  // ---- workspace ----
+  Carver cv;
+  const int nb = cfg.nblocks;
+  const size_t F = sizeof(float);
+  const long V0 = (long)p.D0 * p.H0 * p.W0;
+  p.o_conv0 = cv.take((size_t)N * cfg.init_features * V0 * F);
+  p.o_idx = cv.take((size_t)N * cfg.init_features * p.Vb[0]);
+  p.o_t1.assign(nb, {});
+  size_t dz2 = 0, dap = 0;
+  for (int b = 0; b < nb; ++b) {
+    p.o_x[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b] * F);
+    p.o_g[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b] * F);
+    for (int l = 0; l < cfg.block_layers[b]; ++l) p.o_t1[b].push_back(cv.take((size_t)N * p.mid * p.Vb[b] * F));
+    dz2 = std::max(dz2, (size_t)N * p.mid * p.Vb[b] * F);
+    if (b != nb - 1) {
+      p.o_ap[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b + 1] * F);
+      dap = std::max(dap, (size_t)N * p.ctot_b[b] * p.Vb[b + 1] * F);
+    } else {
+      p.o_ap[b] = 0;
+    }
+  }
+  p.o_dz2 = cv.take(dz2);
+  p.o_dap = cv.take(dap ? dap : 256);
+  p.o_dz0 = cv.take((size_t)N * cfg.init_features * V0 * F);
+  // forward statistics (fp64, zeroed at the start of every training forward)
+  const size_t PAIR = 2 * NREP * sizeof(double);
+  p.o_fstat = cv.cur;
+  p.o_st_conv0 = cv.take(PAIR * cfg.init_features);
+  p.o_st_t1.assign(nb, {});
+  for (int b = 0; b < nb; ++b) {
+    p.o_st_x[b] = cv.take(PAIR * p.ctot_b[b]);
+    for (int l = 0; l < cfg.block_layers[b]; ++l) p.o_st_t1[b].push_back(cv.take(PAIR * p.mid));
+  }
+  p.fstat_bytes = cv.cur - p.o_fstat;
+  // backward statistics (fp64, zeroed at the start of every backward)
+  p.o_bstat = cv.cur;
+  p.o_dg_n0 = cv.take(PAIR * cfg.init_features);
+  p.o_dg_n1.assign(nb, {}); p.o_dg_n2.assign(nb, {}); p.o_dg_tr.clear();
+  for (int b = 0; b < nb; ++b) {
+    p.o_s_x[b] = cv.take(PAIR * p.ctot_b[b]);
+    for (int l = 0; l < cfg.block_layers[b]; ++l) {
+      p.o_dg_n1[b].push_back(cv.take(PAIR * p.layers[b][l].cin));
+      p.o_dg_n2[b].push_back(cv.take(PAIR * p.mid));
+    }
+    if (b != nb - 1) p.o_dg_tr.push_back(cv.take(PAIR * p.ctot_b[b]));
+  }
+  p.o_dg_n5 = cv.take(PAIR * p.ctot_b[nb - 1]);
+  p.bstat_bytes = cv.cur - p.o_bstat;
+  // packed weights
+  p.o_pk_conv0 = cv.take((size_t)7 * stem_krows(cfg.in_channels) * 64 * F);
+  p.o_pk_c1.assign(nb, {}); p.o_pk_c2f.assign(nb, {}); p.o_pk_c2b.assign(nb, {}); p.o_pk_tr.clear();
+  for (int b = 0; b < nb; ++b) {
+    for (int l = 0; l < cfg.block_layers[b]; ++l) {
+      p.o_pk_c1[b].push_back(cv.take((size_t)p.mid * p.layers[b][l].cin * F));
+      p.o_pk_c2f[b].push_back(cv.take((size_t)cfg.growth * p.mid * 27 * F));
+      p.o_pk_c2b[b].push_back(cv.take((size_t)cfg.growth * p.mid * 27 * F));
+    }
+    if (b != nb - 1) p.o_pk_tr.push_back(cv.take((size_t)p.trans[b].cin * p.trans[b].cout * F));
+  }
+  // weight-gradient slabs
+  p.ns_conv0 = stem_wgrad_pick_splits(N, p.D0, p.H0, p.W0);
+  p.o_sl_conv0 = cv.take((size_t)p.ns_conv0 * cfg.in_channels * cfg.init_features * 352 * F);
+  p.o_sl_c1.assign(nb, {}); p.o_sl_c2.assign(nb, {}); p.ns_c1.assign(nb, {}); p.ns_c2.assign(nb, {});
+  p.o_sl_tr.clear(); p.ns_tr.clear();
+  for (int b = 0; b < nb; ++b) {
+    for (int l = 0; l < cfg.block_layers[b]; ++l) {
+      const int ci = p.layers[b][l].cin;
+      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci);
+      const int s2 = wgrad_pick_splits(27, N, p.Db[b], p.Hb[b], p.Wb[b], cfg.growth, p.mid);
+      p.ns_c1[b].push_back(s1); p.ns_c2[b].push_back(s2);
+      p.o_sl_c1[b].push_back(cv.take((size_t)s1 * p.mid * ci * F));
+      p.o_sl_c2[b].push_back(cv.take((size_t)s2 * 27 * cfg.growth * p.mid * F));
+    }
+    if (b != nb - 1) {
+      const int s = wgrad_pick_splits(1, N, p.Db[b + 1], p.Hb[b + 1], p.Wb[b + 1], p.trans[b].cout, p.trans[b].cin);
+      p.ns_tr.push_back(s);
+      p.o_sl_tr.push_back(cv.take((size_t)s * p.trans[b].cout * p.trans[b].cin * F));
+    }
+  }
+  // job tables
+  int nlayers = 0;
+  for (int b = 0; b < nb; ++b) nlayers += cfg.block_layers[b];
+  p.n_run_jobs = nbn;
+  p.n_pack_jobs = 1 + 3 * nlayers + (nb - 1);
+  p.n_grad_jobs = 3 + 6 * nlayers + 3 * (nb - 1) + 2;
+  p.o_jobs_run = cv.take(sizeof(RunStatJob) * p.n_run_jobs);
+  p.o_jobs_pack = cv.take(sizeof(PackJob) * p.n_pack_jobs);
+  p.o_jobs_grad = cv.take(sizeof(GradJob) * p.n_grad_jobs);
+  p.ws_bytes = cv.cur;
+  p.host_jobs_bytes = p.ws_bytes - p.o_jobs_run;
+  if (p.host_jobs) { (void)hipHostFree(p.host_jobs); p.host_jobs = nullptr; }   // (re)allocated lazily by the first forward
+  p.tab_params = nullptr; p.tab_run = nullptr; p.tab_ws = nullptr;
+  return 0;
+}
+
+void plan_free(Plan& p) {
+  if (p.host_jobs) (void)hipHostFree(p.host_jobs);
+  p.host_jobs = nullptr;
+}
+
+static StatPtr statptr(char* ws, size_t o, int C, int off) {
+  StatPtr s;
+  s.sum = reinterpret_cast<double*>(ws + o);
+  s.sq = s.sum + (long)NREP * C;
+  s.stride = C;
+  s.off = off;
+  return s;
+}
+static float* fptr(char* ws, size_t o) { return reinterpret_cast<float*>(ws + o); }
+
+static BnFwd bnfwd(const Plan& p, StatPtr st, const float* params, float* run, long w, long b, long rm, long rv, double count, int training) {
+  BnFwd f;
+  f.st = st;
+  f.rmean = run + rm; f.rvar = run + rv;
+  f.gamma = params + w; f.beta = params + b;
+  f.inv_count = 1.0 / count;
+  f.eps = p.cfg.eps;
+  f.training = training;
+  return f;
+}
+
+// (re)build the device job tables when the buffers they point into change
+static void build_tables(Plan& p, const float* params, float* run, char* ws) {
+  if (p.tab_params == params && p.tab_run == run && p.tab_ws == ws) return;
+  char* hj = static_cast<char*>(p.host_jobs);
+  RunStatJob* rj = reinterpret_cast<RunStatJob*>(hj);
+  PackJob* pj = reinterpret_cast<PackJob*>(hj + (p.o_jobs_pack - p.o_jobs_run));
+  GradJob* gj = reinterpret_cast<GradJob*>(hj + (p.o_jobs_grad - p.o_jobs_run));
+  const NetCfg& c = p.cfg;
+  const int nb = c.nblocks;
+  int ir = 0, ip = 0, ig = 0;
+  p.max_pack = 0; p.max_grad = 0;
+  auto run_job = [&](size_t o, int C, int off, int n, long rm, long rv, double count) {
+    StatPtr s = statptr(ws, o, C, off);
+    RunStatJob j; j.sum = s.sum; j.sq = s.sq; j.stride = C; j.off = off; j.C = n; j.rmean = run ? run + rm : nullptr; j.rvar = run ? run + rv : nullptr; j.count = count;
+    rj[ir++] = j;
+  };
+  auto pack_job = [&](long src, size_t dst, int kind, int M, int C, long count) {
+    PackJob j; j.src = params + src; j.dst = fptr(ws, dst); j.kind = kind; j.M = M; j.C = C; j.count = count;
+    pj[ip++] = j; p.max_pack = std::max(p.max_pack, count);
+  };
+  auto grad_slab = [&](int kind, size_t o, long stride, int ns, int M, int C, long dst, long count) {
+    GradJob j; j.kind = kind; j.src = ws + o; j.stride = stride; j.nsplit = ns; j.off = 0; j.M = M; j.C = C; j.dst_off = dst; j.count = count;
+    gj[ig++] = j; p.max_grad = std::max(p.max_grad, count);
+  };
+  auto grad_bn = [&](size_t o, int C, long dw, long db) {   // pair block: [dbeta replicas][dgamma replicas]
+    StatPtr s = statptr(ws, o, C, 0);
+    GradJob j; j.kind = 3; j.stride = C; j.nsplit = 0; j.off = 0; j.M = 0; j.C = C; j.count = C;
+    j.src = s.sq; j.dst_off = dw; gj[ig++] = j;     // dgamma
+    j.src = s.sum; j.dst_off = db; gj[ig++] = j;    // dbeta
+    p.max_grad = std::max(p.max_grad, (long)C);
+  };
+  const double cnt0 = (double)p.N * p.D0 * p.H0 * p.W0;
+  run_job(p.o_st_conv0, c.init_features, 0, c.init_features, p.r_n0m, p.r_n0v, cnt0);
+  pack_job(p.p_conv0, p.o_pk_conv0, (c.in_channels % 2 == 0) ? 3 : 4, c.init_features, c.in_channels, (long)7 * stem_krows(c.in_channels) * 64);
+  grad_slab(2, p.o_sl_conv0, (long)c.in_channels * c.init_features * 352, p.ns_conv0, c.init_features, c.in_channels, p.p_conv0,
+            (long)c.init_features * c.in_channels * 343);
+  grad_bn(p.o_dg_n0, c.init_features, p.p_n0w, p.p_n0b);
+  for (int b = 0; b < nb; ++b) {
+    const double cnt = (double)p.N * p.Vb[b];
+    for (int l = 0; l < c.block_layers[b]; ++l) {
+      const LayerOff& lo = p.layers[b][l];
+      run_job(p.o_st_x[b], p.ctot_b[b], 0, lo.cin, lo.r1m, lo.r1v, cnt);
+      run_job(p.o_st_t1[b][l], p.mid, 0, p.mid, lo.r2m, lo.r2v, cnt);
+      pack_job(lo.c1, p.o_pk_c1[b][l], 0, p.mid, lo.cin, (long)p.mid * lo.cin);
+      pack_job(lo.c2, p.o_pk_c2f[b][l], 1, c.growth, p.mid, (long)c.growth * p.mid * 27);
+      pack_job(lo.c2, p.o_pk_c2b[b][l], 2, c.growth, p.mid, (long)c.growth * p.mid * 27);
+      grad_bn(p.o_dg_n1[b][l], lo.cin, lo.n1w, lo.n1b);
+      grad_slab(0, p.o_sl_c1[b][l], (long)p.mid * lo.cin, p.ns_c1[b][l], p.mid, lo.cin, lo.c1, (long)p.mid * lo.cin);
+      grad_bn(p.o_dg_n2[b][l], p.mid, lo.n2w, lo.n2b);
+      grad_slab(1, p.o_sl_c2[b][l], (long)27 * c.growth * p.mid, p.ns_c2[b][l], c.growth, p.mid, lo.c2, (long)c.growth * p.mid * 27);
+    }
+    if (b != nb - 1) {
+      const TransOff& t = p.trans[b];
+      run_job(p.o_st_x[b], p.ctot_b[b], 0, t.cin, t.rm, t.rv, cnt);
+      pack_job(t.cw, p.o_pk_tr[b], 0, t.cout, t.cin, (long)t.cout * t.cin);
+      grad_bn(p.o_dg_tr[b], t.cin, t.nw, t.nb);
+      grad_slab(0, p.o_sl_tr[b], (long)t.cout * t.cin, p.ns_tr[b], t.cout, t.cin, t.cw, (long)t.cout * t.cin);
+    } else {
+      run_job(p.o_st_x[b], p.ctot_b[b], 0, p.ctot_b[b], p.r_n5m, p.r_n5v, cnt);
+      grad_bn(p.o_dg_n5, p.ctot_b[b], p.p_n5w, p.p_n5b);
+    }
+  }
+  p.n_run_jobs = ir; p.n_pack_jobs = ip; p.n_grad_jobs = ig;
+  p.tab_params = params; p.tab_run = run; p.tab_ws = ws;
+}
+
+static DropCfg dropcfg(const Plan& p, uint64_t seed, int layer, int training) {
+  DropCfg d;
+  d.seed = seed; d.layer = layer;
+  d.p = training ? p.cfg.dropout_p : 0.f;
+  return d;
+}
+
+int plan_forward(Plan& p, const float* params, float* run, const float* x, char* ws, float* out, int training, uint64_t seed,
+                 hipStream_t stream) {
+  MMNN_REQUIRE(params && run && x && ws && out, "forward: null buffer");
+  MMNN_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)params & 15) == 0 && ((uintptr_t)x & 15) == 0, "forward: buffers must be 256/16-byte aligned");
+  const NetCfg& c = p.cfg;
+  const int nb = c.nblocks, N = p.N;
+  if (!p.host_jobs) {   // pinned staging for the job tables: the only memory the plan owns
+    MMNN_HIP(hipHostMalloc(&p.host_jobs, p.host_jobs_bytes, hipHostMallocDefault));
+    memset(p.host_jobs, 0, p.host_jobs_bytes);
+  }
+  build_tables(p, params, run, ws);
+  MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
+  if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
+  int rc = launch_pack(reinterpret_cast<const PackJob*>(ws + p.o_jobs_pack), p.n_pack_jobs, p.max_pack, stream);
+  if (rc) return rc;
+
+  const double cnt0 = (double)N * p.D0 * p.H0 * p.W0;
+  {  // stem
+    StemConvArgs a;
+    a.N = N; a.Cin = c.in_channels; a.D = p.D; a.H = p.H; a.W = p.W; a.Do = p.D0; a.Ho = p.H0; a.Wo = p.W0; a.M = c.init_features;
+    a.x = x; a.wp = fptr(ws, p.o_pk_conv0); a.out = fptr(ws, p.o_conv0);
+    a.st_out = statptr(ws, p.o_st_conv0, c.init_features, 0);
+    if (!training) a.st_out.sum = nullptr;
+    if ((rc = launch_stem_conv(a, stream))) return rc;
+    StemPoolArgs q;
+    q.N = N; q.C = c.init_features; q.Di = p.D0; q.Hi = p.H0; q.Wi = p.W0; q.Do = p.Db[0]; q.Ho = p.Hb[0]; q.Wo = p.Wb[0];
+    q.x = fptr(ws, p.o_conv0);
+    q.bn = bnfwd(p, statptr(ws, p.o_st_conv0, c.init_features, 0), params, run, p.p_n0w, p.p_n0b, p.r_n0m, p.r_n0v, cnt0, training);
+    q.out = fptr(ws, p.o_x[0]); q.out_ns = (long)p.ctot_b[0] * p.Vb[0];
+    q.idx = reinterpret_cast<unsigned char*>(ws + p.o_idx);
+    q.st_out = statptr(ws, p.o_st_x[0], p.ctot_b[0], 0);
+    if (!training) q.st_out.sum = nullptr;
+    if ((rc = launch_stem_pool(q, stream))) return rc;
+  }
+  int layer_id = 0;
+  for (int b = 0; b < nb; ++b) {
+    const double cnt = (double)N * p.Vb[b];
+    const long xns = (long)p.ctot_b[b] * p.Vb[b];
+    for (int l = 0; l < c.block_layers[b]; ++l, ++layer_id) {
+      const LayerOff& lo = p.layers[b][l];
+      FpropArgs a;
+      memset(&a, 0, sizeof(a));
+      a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
+      // conv1: ReLU(BN(concat)) -> T1
+      a.Cin = lo.cin; a.M = p.mid;
+      a.in0 = fptr(ws, p.o_x[b]); a.in0_ns = xns; a.in0_coff = 0;
+      a.bn_in = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, training);
+      a.w = fptr(ws, p.o_pk_c1[b][l]); a.w_ld = p.mid;
+      a.out = fptr(ws, p.o_t1[b][l]); a.out_ns = (long)p.mid * p.Vb[b]; a.out_coff = 0;
+      a.st_out = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
+      if (!training) a.st_out.sum = nullptr;
+      if ((rc = launch_fprop(a, 1, PRO_BNRELU, EPI_STORE_STATS, stream))) return rc;
+      // conv2: ReLU(BN(T1)) -> growth new channels of the concat buffer (+ channel dropout)
+      FpropArgs e;
+      memset(&e, 0, sizeof(e));
+      e.N = N; e.D = p.Db[b]; e.H = p.Hb[b]; e.W = p.Wb[b];
+      e.Cin = p.mid; e.M = c.growth;
+      e.in0 = fptr(ws, p.o_t1[b][l]); e.in0_ns = (long)p.mid * p.Vb[b]; e.in0_coff = 0;
+      e.bn_in = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, training);
+      e.w = fptr(ws, p.o_pk_c2f[b][l]); e.w_ld = c.growth;
+      e.out = fptr(ws, p.o_x[b]); e.out_ns = xns; e.out_coff = lo.cin;
+      e.drop_out = dropcfg(p, seed, layer_id, training);
+      e.st_out = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);
+      if (!training) e.st_out.sum = nullptr;
+      if ((rc = launch_fprop(e, 27, PRO_BNRELU, EPI_STORE_STATS, stream))) return rc;
+    }
+    if (b != nb - 1) {
+      const TransOff& t = p.trans[b];
+      PoolFwdArgs q;
+      q.N = N; q.C = t.cin; q.D = p.Db[b]; q.H = p.Hb[b]; q.W = p.Wb[b];
+      q.x = fptr(ws, p.o_x[b]); q.x_ns = xns;
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, t.nw, t.nb, t.rm, t.rv, cnt, training);
+      q.out = fptr(ws, p.o_ap[b]);
+      if ((rc = launch_bnrelu_avgpool(q, stream))) return rc;
+      FpropArgs a;
+      memset(&a, 0, sizeof(a));
+      a.N = N; a.D = p.Db[b + 1]; a.H = p.Hb[b + 1]; a.W = p.Wb[b + 1];
+      a.Cin = t.cin; a.M = t.cout;
+      a.in0 = fptr(ws, p.o_ap[b]); a.in0_ns = (long)t.cin * p.Vb[b + 1]; a.in0_coff = 0;
+      a.w = fptr(ws, p.o_pk_tr[b]); a.w_ld = t.cout;
+      a.out = fptr(ws, p.o_x[b + 1]); a.out_ns = (long)p.ctot_b[b + 1] * p.Vb[b + 1]; a.out_coff = 0;
+      a.st_out = statptr(ws, p.o_st_x[b + 1], p.ctot_b[b + 1], 0);
+      if (!training) a.st_out.sum = nullptr;
+      if ((rc = launch_fprop(a, 1, PRO_NONE, EPI_STORE_STATS, stream))) return rc;
+    } else {
+      BnApplyArgs q;
+      q.N = N; q.C = p.ctot_b[b]; q.V = p.Vb[b];
+      q.x = fptr(ws, p.o_x[b]); q.x_ns = xns;
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, cnt, training);
+      q.out = out;
+      if ((rc = launch_bn_apply(q, stream))) return rc;
+    }
+  }
+  if (training) {
+    if ((rc = launch_running_stats(reinterpret_cast<const RunStatJob*>(ws + p.o_jobs_run), p.n_run_jobs, c.momentum, stream))) return rc;
+  }
+  return 0;
+}
+
+int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params, int accumulate,
+                  uint64_t seed, hipStream_t stream) {
+  MMNN_REQUIRE(params && x && ws && grad_out && grad_params, "backward: null buffer");
+  MMNN_REQUIRE(p.tab_ws == ws && p.tab_params == params, "backward: must follow a training forward on the same buffers");
+  const NetCfg& c = p.cfg;
+  const int nb = c.nblocks, N = p.N;
+  float* run = p.tab_run;
+  int rc;
+  MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
+  auto sptr = [&](int b, int off) { return statptr(ws, p.o_s_x[b], p.ctot_b[b], off); };
+  auto concat_grad = [&](int b, int off) {   // BN-backward of concat channels [off, ...) of block b (gammas folded into G)
+    BnBwd g;
+    g.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], off);
+    g.s = sptr(b, off);
+    g.gamma = nullptr;
+    g.inv_count = 1.0 / ((double)N * p.Vb[b]);
+    g.eps = c.eps;
+    return g;
+  };
+  {  // norm5: first contribution to the last block's G
+    const int b = nb - 1;
+    ConsumerBwdArgs a;
+    a.N = N; a.C = p.ctot_b[b]; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b]; a.mode = 0;
+    a.dy = grad_out;
+    a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, (double)N * p.Vb[b], 1);
+    a.g = fptr(ws, p.o_g[b]); a.g_ns = a.x_ns;
+    StatPtr dg = statptr(ws, p.o_dg_n5, p.ctot_b[b], 0);
+    a.dbeta = dg.sum; a.dgamma = dg.sq;
+    a.s_acc = sptr(b, 0);
+    if ((rc = launch_consumer_bwd(a, stream))) return rc;
+  }
+  int layer_id = 0;
+  for (int b = 0; b < nb; ++b) layer_id += c.block_layers[b];
+  for (int b = nb - 1; b >= 0; --b) {
+    const double cnt = (double)N * p.Vb[b];
+    const long xns = (long)p.ctot_b[b] * p.Vb[b];
+    const long tns = (long)p.mid * p.Vb[b];
+    for (int l = c.block_layers[b] - 1; l >= 0; --l) {
+      --layer_id;
+      const LayerOff& lo = p.layers[b][l];
+      const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+      const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+      const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0);
+      const StatPtr dg1 = statptr(ws, p.o_dg_n1[b][l], lo.cin, 0);
+      const DropCfg drop = dropcfg(p, seed, layer_id, 1);
+      // conv2 data gradient -> dZ2 (ReLU mask of norm2 applied) + dgamma2/dbeta2
+      FpropArgs a;
+      memset(&a, 0, sizeof(a));
+      a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
+      a.Cin = c.growth; a.M = p.mid;
+      a.in0 = fptr(ws, p.o_g[b]); a.in0_ns = xns; a.in0_coff = lo.cin;
+      a.in1 = fptr(ws, p.o_x[b]); a.in1_ns = xns; a.in1_coff = lo.cin;
+      a.gr_in = concat_grad(b, lo.cin);
+      a.drop_in = drop;
+      a.w = fptr(ws, p.o_pk_c2b[b][l]); a.w_ld = p.mid;
+      a.out = fptr(ws, p.o_dz2); a.out_ns = tns; a.out_coff = 0;
+      a.ex = fptr(ws, p.o_t1[b][l]); a.ex_ns = tns; a.ex_coff = 0;
+      a.ebn = bn2;
+      a.dbeta = dg2.sum; a.dgamma = dg2.sq;
+      if ((rc = launch_fprop(a, 27, PRO_GRAD, EPI_MASK_STORE, stream))) return rc;
+      // conv2 weight gradient
+      WgradArgs w2;
+      memset(&w2, 0, sizeof(w2));
+      w2.N = N; w2.D = p.Db[b]; w2.H = p.Hb[b]; w2.W = p.Wb[b];
+      w2.M = c.growth; w2.Cin = p.mid;
+      w2.g0 = a.in0; w2.g0_ns = xns; w2.g0_coff = lo.cin;
+      w2.g1 = a.in1; w2.g1_ns = xns; w2.g1_coff = lo.cin;
+      w2.gr = a.gr_in; w2.drop = drop;
+      w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
+      w2.bn = bn2;
+      w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
+      if ((rc = launch_wgrad(w2, 27, PRO_BNRELU, stream))) return rc;
+      // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
+      BnBwd g1;
+      g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
+      g1.s = dg2;
+      g1.gamma = params + lo.n2w;
+      g1.inv_count = 1.0 / cnt;
+      g1.eps = c.eps;
+      // conv1 data gradient -> G[0:cin) += gamma1 * mask * (...), dgamma1/dbeta1, S1/S2
+      FpropArgs d;
+      memset(&d, 0, sizeof(d));
+      d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
+      d.Cin = p.mid; d.M = lo.cin;
+      d.in0 = fptr(ws, p.o_dz2); d.in0_ns = tns; d.in0_coff = 0;
+      d.in1 = fptr(ws, p.o_t1[b][l]); d.in1_ns = tns; d.in1_coff = 0;
+      d.gr_in = g1;
+      d.w = params + lo.c1; d.w_ld = lo.cin;
+      d.out = fptr(ws, p.o_g[b]); d.out_ns = xns; d.out_coff = 0;
+      d.ex = fptr(ws, p.o_x[b]); d.ex_ns = xns; d.ex_coff = 0;
+      d.ebn = bn1;
+      d.dbeta = dg1.sum; d.dgamma = dg1.sq;
+      d.s_acc = sptr(b, 0);
+      if ((rc = launch_fprop(d, 1, PRO_GRAD, EPI_MASK_ACCUM, stream))) return rc;
+      // conv1 weight gradient
+      WgradArgs w1;
+      memset(&w1, 0, sizeof(w1));
+      w1.N = N; w1.D = p.Db[b]; w1.H = p.Hb[b]; w1.W = p.Wb[b];
+      w1.M = p.mid; w1.Cin = lo.cin;
+      w1.g0 = d.in0; w1.g0_ns = tns; w1.g0_coff = 0;
+      w1.g1 = d.in1; w1.g1_ns = tns; w1.g1_coff = 0;
+      w1.gr = g1;
+      w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
+      w1.bn = bn1;
+      w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
+      if ((rc = launch_wgrad(w1, 1, PRO_BNRELU, stream))) return rc;
+    }
+    if (b > 0) {
+      const int pb = b - 1;
+      const TransOff& t = p.trans[pb];
+      const long pxns = (long)p.ctot_b[pb] * p.Vb[pb];
+      // transition conv weight gradient (input = pooled activations)
+      WgradArgs w;
+      memset(&w, 0, sizeof(w));
+      w.N = N; w.D = p.Db[b]; w.H = p.Hb[b]; w.W = p.Wb[b];
+      w.M = t.cout; w.Cin = t.cin;
+      w.g0 = fptr(ws, p.o_g[b]); w.g0_ns = xns; w.g0_coff = 0;
+      w.g1 = fptr(ws, p.o_x[b]); w.g1_ns = xns; w.g1_coff = 0;
+      w.gr = concat_grad(b, 0);
+      w.x = fptr(ws, p.o_ap[pb]); w.x_ns = (long)t.cin * p.Vb[b]; w.x_coff = 0;
+      w.slab = fptr(ws, p.o_sl_tr[pb]); w.slab_stride = (long)t.cout * t.cin; w.nsplit = p.ns_tr[pb];
+      if ((rc = launch_wgrad(w, 1, PRO_NONE, stream))) return rc;
+      // transition conv data gradient -> gradient wrt the pooled activations
+      FpropArgs d;
+      memset(&d, 0, sizeof(d));
+      d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
+      d.Cin = t.cout; d.M = t.cin;
+      d.in0 = w.g0; d.in0_ns = xns; d.in0_coff = 0;
+      d.in1 = w.g1; d.in1_ns = xns; d.in1_coff = 0;
+      d.gr_in = w.gr;
+      d.w = params + t.cw; d.w_ld = t.cin;
+      d.out = fptr(ws, p.o_dap); d.out_ns = (long)t.cin * p.Vb[b]; d.out_coff = 0;
+      if ((rc = launch_fprop(d, 1, PRO_GRAD, EPI_STORE, stream))) return rc;
+      // un-pool + ReLU + BN of the transition: first contribution to the previous block's G
+      ConsumerBwdArgs q;
+      q.N = N; q.C = t.cin; q.D = p.Db[pb]; q.H = p.Hb[pb]; q.W = p.Wb[pb]; q.mode = 1;
+      q.dy = fptr(ws, p.o_dap);
+      q.x = fptr(ws, p.o_x[pb]); q.x_ns = pxns;
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[pb], p.ctot_b[pb], 0), params, run, t.nw, t.nb, t.rm, t.rv, (double)N * p.Vb[pb], 1);
+      q.g = fptr(ws, p.o_g[pb]); q.g_ns = pxns;
+      StatPtr dg = statptr(ws, p.o_dg_tr[pb], t.cin, 0);
+      q.dbeta = dg.sum; q.dgamma = dg.sq;
+      q.s_acc = sptr(pb, 0);
+      if ((rc = launch_consumer_bwd(q, stream))) return rc;
+    } else {
+      const double cnt0 = (double)N * p.D0 * p.H0 * p.W0;
+      StemPoolBwdArgs q;
+      q.N = N; q.C = c.init_features; q.Di = p.D0; q.Hi = p.H0; q.Wi = p.W0; q.Do = p.Db[0]; q.Ho = p.Hb[0]; q.Wo = p.Wb[0];
+      q.x = fptr(ws, p.o_conv0);
+      q.bn = bnfwd(p, statptr(ws, p.o_st_conv0, c.init_features, 0), params, run, p.p_n0w, p.p_n0b, p.r_n0m, p.r_n0v, cnt0, 1);
+      q.g = fptr(ws, p.o_g[0]); q.g_ns = xns;
+      q.xp = fptr(ws, p.o_x[0]); q.xp_ns = xns;
+      q.gr = concat_grad(0, 0);
+      q.idx = reinterpret_cast<const unsigned char*>(ws + p.o_idx);
+      q.dz = fptr(ws, p.o_dz0);
+      StatPtr dg = statptr(ws, p.o_dg_n0, c.init_features, 0);
+      q.dbeta = dg.sum; q.dgamma = dg.sq;
+      if ((rc = launch_stem_pool_bwd(q, stream))) return rc;
+      StemWgradArgs w;
+      w.N = N; w.Cin = c.in_channels; w.D = p.D; w.H = p.H; w.W = p.W; w.Do = p.D0; w.Ho = p.H0; w.Wo = p.W0; w.M = c.init_features;
+      w.x = x; w.dz = fptr(ws, p.o_dz0); w.y = fptr(ws, p.o_conv0);
+      w.gr.st = statptr(ws, p.o_st_conv0, c.init_features, 0);
+      w.gr.s = dg;
+      w.gr.gamma = params + p.p_n0w;
+      w.gr.inv_count = 1.0 / cnt0;
+      w.gr.eps = c.eps;
+      w.slab = fptr(ws, p.o_sl_conv0); w.slab_stride = (long)c.in_channels * c.init_features * 352; w.nsplit = p.ns_conv0;
+      if ((rc = launch_stem_wgrad(w, stream))) return rc;
+    }
+  }
+  return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), p.n_grad_jobs, p.max_grad, grad_params, accumulate, stream);
+}
+
+long plan_ws_offset(const Plan& p, const char* name, int i, int j) {
+  const std::string s(name);
+  const int nb = p.cfg.nblocks;
+  auto okb = [&](int b) { return b >= 0 && b < nb; };
+  auto okl = [&](int b, int l) { return okb(b) && l >= 0 && l < p.cfg.block_layers[b]; };
+  if (s == "conv0") return (long)p.o_conv0;
+  if (s == "idx") return (long)p.o_idx;
+  if (s == "dz0") return (long)p.o_dz0;
+  if (s == "dz2") return (long)p.o_dz2;
+  if (s == "dap") return (long)p.o_dap;
+  if (s == "x" && okb(i)) return (long)p.o_x[i];
+  if (s == "g" && okb(i)) return (long)p.o_g[i];
+  if (s == "ap" && okb(i) && i < nb - 1) return (long)p.o_ap[i];
+  if (s == "t1" && okl(i, j)) return (long)p.o_t1[i][j];
+  if (s == "st_conv0") return (long)p.o_st_conv0;
+  if (s == "st_x" && okb(i)) return (long)p.o_st_x[i];
+  if (s == "st_t1" && okl(i, j)) return (long)p.o_st_t1[i][j];
+  if (s == "s_x" && okb(i)) return (long)p.o_s_x[i];
+  if (s == "pk_c1" && okl(i, j)) return (long)p.o_pk_c1[i][j];
+  if (s == "pk_c2f" && okl(i, j)) return (long)p.o_pk_c2f[i][j];
+  if (s == "pk_c2b" && okl(i, j)) return (long)p.o_pk_c2b[i][j];
+  if (s == "pk_conv0") return (long)p.o_pk_conv0;
+  return -1;
+}
+
+}  // namespace mmnn

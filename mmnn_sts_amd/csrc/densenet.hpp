@@ -1,0 +1,77 @@
+// Host-side plan of the 3-D DenseNet backbone (models/densenet.py:196-231): workspace layout, parameter layout and
+// the launch sequences of forward / backward.  PyTorch owns every device buffer; the plan owns only small host tables.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "elementwise.hpp"
+
+namespace mmnn {
+
+constexpr int MAX_BLOCKS = 8;
+
+struct NetCfg {
+  int in_channels, init_features, growth, bn_size, nblocks;
+  int block_layers[MAX_BLOCKS];
+  float eps, momentum, dropout_p;
+};
+
+struct LayerOff {          // offsets (floats) into the flat parameter / running-stat buffers
+  long n1w, n1b, c1, n2w, n2b, c2;
+  long r1m, r1v, r2m, r2v;
+  int cin;                 // channels seen by norm1 / conv1
+};
+struct TransOff { long nw, nb, cw; long rm, rv; int cin, cout; };
+
+struct Plan {
+  NetCfg cfg;
+  int N, D, H, W;
+  int D0, H0, W0;                         // conv0 output extent
+  int Db[MAX_BLOCKS], Hb[MAX_BLOCKS], Wb[MAX_BLOCKS], Vb[MAX_BLOCKS];
+  int cin_b[MAX_BLOCKS], ctot_b[MAX_BLOCKS];
+  int mid;                                // bn_size * growth
+  // parameters
+  long p_conv0, p_n0w, p_n0b, r_n0m, r_n0v, p_n5w, p_n5b, r_n5m, r_n5v;
+  std::vector<std::vector<LayerOff>> layers;
+  std::vector<TransOff> trans;
+  long n_params, n_runstats;
+  int n_bn;
+  // workspace (byte offsets)
+  size_t ws_bytes;
+  size_t o_conv0, o_idx, o_x[MAX_BLOCKS], o_g[MAX_BLOCKS], o_ap[MAX_BLOCKS], o_dz2, o_dap, o_dz0;
+  std::vector<std::vector<size_t>> o_t1;
+  // fp64 statistics: one zero-filled region for forward sums, one for backward sums
+  size_t o_fstat, fstat_bytes, o_bstat, bstat_bytes;
+  size_t o_st_conv0, o_st_x[MAX_BLOCKS];          // inside fstat: [2][NREP][C]
+  std::vector<std::vector<size_t>> o_st_t1;
+  size_t o_s_x[MAX_BLOCKS];                       // inside bstat: S1/S2 [2][NREP][ctot]
+  size_t o_dg_n0, o_dg_n5;                        // dgamma/dbeta [2][NREP][C]
+  std::vector<std::vector<size_t>> o_dg_n1, o_dg_n2;
+  std::vector<size_t> o_dg_tr;
+  // packed weights
+  size_t o_pk_conv0;
+  std::vector<std::vector<size_t>> o_pk_c1, o_pk_c2f, o_pk_c2b;
+  std::vector<size_t> o_pk_tr;
+  // weight-gradient slabs
+  size_t o_sl_conv0; int ns_conv0;
+  std::vector<std::vector<size_t>> o_sl_c1, o_sl_c2;
+  std::vector<std::vector<int>> ns_c1, ns_c2;
+  std::vector<size_t> o_sl_tr; std::vector<int> ns_tr;
+  // device job tables (inside the workspace) + pinned host staging
+  size_t o_jobs_run, o_jobs_pack, o_jobs_grad;
+  void* host_jobs = nullptr; size_t host_jobs_bytes = 0;
+  // cached identity of the buffers the tables were built for
+  const float* tab_params = nullptr; float* tab_run = nullptr; char* tab_ws = nullptr;
+  int n_run_jobs = 0, n_pack_jobs = 0, n_grad_jobs = 0; long max_pack = 0, max_grad = 0;
+};
+
+int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W);
+void plan_free(Plan& p);
+int plan_forward(Plan& p, const float* params, float* runstats, const float* x, char* ws, float* out, int training,
+                 uint64_t seed, hipStream_t stream);
+int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params,
+                  int accumulate, uint64_t seed, hipStream_t stream);
+long plan_ws_offset(const Plan& p, const char* name, int i, int j);
+
+}  // namespace mmnn

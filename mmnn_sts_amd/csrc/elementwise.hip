@@ -1,0 +1,225 @@
+#include "elementwise.hpp"
+
+namespace mmnn {
+
+// block-wide sum of two floats -> thread 0 (256 threads)
+__device__ __forceinline__ void block_sum2(float& s0, float& s1, float (*red)[4]) {
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bnrelu_avgpool_kernel(const PoolFwdArgs a) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
+  const int Vo = Do * Ho * Wo, V = a.D * a.H * a.W;
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float* xc = a.x + (long)n * a.x_ns + (long)c * V;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < Vo; p += gridDim.x * 256) {
+    const int wo = p % Wo, ho = (p / Wo) % Ho, d_o = p / (Wo * Ho);
+    float s = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const float* row = xc + ((long)(2 * d_o + kd) * a.H + 2 * ho + kh) * a.W + 2 * wo;
+        s += fmaxf(fmaf(ca, row[0], cb), 0.f) + fmaxf(fmaf(ca, row[1], cb), 0.f);
+      }
+    a.out[((long)n * a.C + c) * Vo + p] = s * 0.125f;
+  }
+}
+
+int launch_bnrelu_avgpool(const PoolFwdArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.D >= 2 && a.H >= 2 && a.W >= 2, "avgpool: extent too small (%d,%d,%d)", a.D, a.H, a.W);
+  MMNN_REQUIRE(a.N <= 65535 && a.C <= 65535, "avgpool: grid out of range");
+  const int Vo = (a.D / 2) * (a.H / 2) * (a.W / 2);
+  hipLaunchKernelGGL(bnrelu_avgpool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_apply_kernel(const BnApplyArgs a) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float* xc = a.x + (long)n * a.x_ns + (long)c * a.V;
+  float* oc = a.out + ((long)n * a.C + c) * a.V;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < a.V; v += gridDim.x * 256) oc[v] = fmaf(ca, xc[v], cb);
+}
+
+int launch_bn_apply(const BnApplyArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.V > 0 && a.N <= 65535 && a.C <= 65535, "bn_apply: bad extent");
+  int gx = cdiv(a.V, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) consumer_bwd_kernel(const ConsumerBwdArgs a) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int V = a.D * a.H * a.W;
+  const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float gam = a.bn.gamma[c];
+  const float* xc = a.x + (long)n * a.x_ns + (long)c * V;
+  float* gc = a.g + (long)n * a.g_ns + (long)c * V;
+  const float* dyc = a.dy + ((long)n * a.C + c) * (a.mode == 0 ? V : Do * Ho * Wo);
+  float s0 = 0.f, s1 = 0.f;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+    const float x = xc[v];
+    float z;
+    if (a.mode == 0) {
+      z = dyc[v];
+    } else {
+      const int w = v % a.W, h = (v / a.W) % a.H, d = v / (a.W * a.H);
+      const int pw = w >> 1, ph = h >> 1, pd = d >> 1;
+      z = 0.f;
+      if (pw < Wo && ph < Ho && pd < Do && fmaf(ca, x, cb) > 0.f) z = 0.125f * dyc[((long)pd * Ho + ph) * Wo + pw];
+    }
+    gc[v] = gam * z;
+    s0 += z;
+    s1 += z * (x - mu) * rs;
+  }
+  block_sum2(s0, s1, red);
+  if (threadIdx.x == 0) {
+    const int rep = blockIdx.x & (NREP - 1);
+    atomicAdd(a.dbeta + (long)rep * a.C + c, (double)s0);
+    atomicAdd(a.dgamma + (long)rep * a.C + c, (double)s1);
+    atomicAdd(a.s_acc.sum + (long)rep * a.s_acc.stride + a.s_acc.off + c, (double)gam * s0);
+    atomicAdd(a.s_acc.sq + (long)rep * a.s_acc.stride + a.s_acc.off + c, (double)gam * s1);
+  }
+}
+
+int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "consumer_bwd: bad extent");
+  MMNN_REQUIRE(a.mode == 0 || a.mode == 1, "consumer_bwd: bad mode");
+  const int V = a.D * a.H * a.W;
+  int gx = cdiv(V, 1024);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(consumer_bwd_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) running_stats_kernel(const RunStatJob* jobs, float momentum) {
+  const RunStatJob j = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < j.C; c += 256) {
+    const double mean = stat_total(j.sum, j.stride, j.off + c) / j.count;
+    double var = stat_total(j.sq, j.stride, j.off + c) / j.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unb = j.count > 1.0 ? var * j.count / (j.count - 1.0) : var;
+    j.rmean[c] = (float)((1.0 - momentum) * (double)j.rmean[c] + momentum * mean);
+    j.rvar[c] = (float)((1.0 - momentum) * (double)j.rvar[c] + momentum * unb);
+  }
+}
+
+int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, hipStream_t stream) {
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(running_stats_kernel, dim3(njobs), dim3(256), 0, stream, jobs_dev, momentum);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_kernel(const PackJob* jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < j.count; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    if (j.kind == 0) {                      // dst[c][m] = w[m][c]
+      const int m = (int)(i % j.M), c = (int)(i / j.M);
+      v = j.src[(long)m * j.C + c];
+    } else if (j.kind == 1) {               // dst[c*27+t][m] = w[m][c][t]
+      const int m = (int)(i % j.M);
+      const long k = i / j.M;
+      v = j.src[(long)m * j.C * 27 + k];
+    } else if (j.kind == 2) {               // dst[m*27+t][c] = w[m][c][26-t]
+      const int c = (int)(i % j.C);
+      const long k = i / j.C;
+      const int t = (int)(k % 27), m = (int)(k / 27);
+      v = j.src[((long)m * j.C + c) * 27 + 26 - t];
+    } else if (j.kind == 3) {               // dst[kd][c*49 + kh*7 + kw][64] = w[m][c][kd][kh][kw]
+      const int m = (int)(i % 64);
+      long k = i / 64;
+      const int r = (int)(k % (j.C * 49)), kd = (int)(k / (j.C * 49));
+      const int c = r / 49, hw = r % 49;
+      if (m < j.M) v = j.src[(((long)m * j.C + c) * 7 + kd) * 49 + hw];
+    } else {                                // dst[kd][c*56 + kh*8 + kw][64], kw == 7 is zero padding
+      const int m = (int)(i % 64);
+      long k = i / 64;
+      const int r = (int)(k % (j.C * 56)), kd = (int)(k / (j.C * 56));
+      const int c = r / 56, kh = (r % 56) / 8, kw = r % 8;
+      if (m < j.M && kw < 7) v = j.src[((((long)m * j.C + c) * 7 + kd) * 7 + kh) * 7 + kw];
+    }
+    j.dst[i] = v;
+  }
+}
+
+int launch_pack(const PackJob* jobs_dev, int njobs, long max_count, hipStream_t stream) {
+  if (njobs <= 0) return 0;
+  MMNN_REQUIRE(njobs <= 65535, "pack: too many jobs");
+  int gx = cdiv(max_count, 256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(pack_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) finalize_kernel(const GradJob* jobs, float* grad, int accumulate) {
+  const GradJob j = jobs[blockIdx.y];
+  float* dst = grad + j.dst_off;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < j.count; i += (long)gridDim.x * 256) {
+    float v;
+    if (j.kind == 3) {
+      const double* s = static_cast<const double*>(j.src);
+      double t = 0.0;
+      for (int r = 0; r < NREP; ++r) t += s[(long)r * j.stride + j.off + i];
+      v = (float)t;
+    } else {
+      const float* s = static_cast<const float*>(j.src);
+      long si;
+      if (j.kind == 0) {
+        si = i;
+      } else if (j.kind == 1) {             // dst[m][c][tap] <- slab[tap][m][c]
+        const int tap = (int)(i % 27);
+        const long mc = i / 27;
+        si = (long)tap * j.M * j.C + mc;
+      } else {                              // dst[m][c][tap343] <- slab[c][m][352]
+        const int tap = (int)(i % 343);
+        const long mc = i / 343;
+        const int c = (int)(mc % j.C), m = (int)(mc / j.C);
+        si = ((long)c * j.M + m) * 352 + tap;
+      }
+      float t = 0.f;
+      for (int sp = 0; sp < j.nsplit; ++sp) t += s[(long)sp * j.stride + si];
+      v = t;
+    }
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
+int launch_finalize(const GradJob* jobs_dev, int njobs, long max_count, float* grad, int accumulate, hipStream_t stream) {
+  if (njobs <= 0) return 0;
+  MMNN_REQUIRE(njobs <= 65535 && grad, "finalize: bad arguments");
+  int gx = cdiv(max_count, 256 * 2);
+  if (gx < 1) gx = 1;
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(finalize_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, grad, accumulate);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmnn

@@ -1,0 +1,15 @@
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace mmnn {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+}  // namespace mmnn

@@ -1,0 +1,67 @@
+// Host-side dispatch of the implicit-GEMM convolution template (fprop.hpp): picks a tile shape from the
+// spatial extent and the number of output rows, validates every shape the kernel indexes with, and launches.
+#include "fprop.hpp"
+
+namespace mmnn {
+
+template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
+static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
+  auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
+  const size_t smem = C::smem_bytes(a.Cin);
+  MMNN_REQUIRE(smem <= 160 * 1024, "fprop: %zu bytes of LDS needed (Cin=%d) exceeds 160 KiB", smem, a.Cin);
+  static size_t configured = 0;
+  if (smem > configured) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = smem;
+  }
+  long tiles;
+  if (TAPS == 27) tiles = (long)a.N * cdiv(a.D, TD) * cdiv(a.H, TH) * cdiv(a.W, TW);
+  else tiles = (long)a.N * cdiv((long)a.D * a.H * a.W, C::V_B);
+  const int mtiles = cdiv(a.M, C::M_B);
+  MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31) && mtiles <= 65535, "fprop: grid out of range");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)mtiles), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int TAPS, int PRO, int EPI>
+static int dispatch(const FpropArgs& a, hipStream_t s) {
+  const long V = (long)a.D * a.H * a.W;
+  if (TAPS == 1) {
+    const long big_blocks = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
+    if (big_blocks >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 2, 16, 1, 1, 128>(a, s);
+    return launch_cfg<1, PRO, EPI, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
+  }
+  if (a.M <= 32) {
+    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 2, 8, 2, 4, 32>(a, s);
+    if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 4, 1, 2, 8, 2, 8, 16>(a, s);
+    if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 2, 1, 1, 8, 2, 4, 8>(a, s);
+    return launch_cfg<27, PRO, EPI, 1, 2, 1, 1, 8, 4, 4, 4>(a, s);
+  }
+  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 4, 1, 4, 32>(a, s);
+  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 4, 2, 4, 16>(a, s);
+  if (a.W > 4) return launch_cfg<27, PRO, EPI, 2, 2, 2, 1, 4, 2, 4, 8>(a, s);
+  return launch_cfg<27, PRO, EPI, 2, 2, 2, 1, 4, 4, 4, 4>(a, s);
+}
+
+int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "fprop: non-positive extent");
+  MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "fprop: volume too large for 32-bit voxel indices");
+  MMNN_REQUIRE(a.in0 && a.w && a.out && a.w_ld >= a.M, "fprop: null operand or w_ld < M");
+  MMNN_REQUIRE(pro != PRO_GRAD || a.in1, "fprop: PRO_GRAD needs the normalised tensor (in1)");
+  MMNN_REQUIRE((epi != EPI_MASK_STORE && epi != EPI_MASK_ACCUM) || (a.ex && a.dgamma && a.dbeta), "fprop: mask epilogue operands missing");
+#define MMNN_CASE(T, P, E) \
+  if (taps == T && pro == P && epi == E) return dispatch<T, P, E>(a, stream);
+  MMNN_CASE(1, PRO_BNRELU, EPI_STORE_STATS)    // dense-layer conv1 forward
+  MMNN_CASE(1, PRO_NONE, EPI_STORE_STATS)      // transition conv forward (input already pooled)
+  MMNN_CASE(1, PRO_GRAD, EPI_MASK_ACCUM)       // conv1 data gradient -> G of the block buffer
+  MMNN_CASE(1, PRO_GRAD, EPI_STORE)            // transition conv data gradient
+  MMNN_CASE(27, PRO_BNRELU, EPI_STORE_STATS)   // dense-layer conv2 forward
+  MMNN_CASE(27, PRO_GRAD, EPI_MASK_STORE)      // conv2 data gradient
+#undef MMNN_CASE
+  set_error("fprop: unsupported (taps=%d, pro=%d, epi=%d)", taps, pro, epi);
+  return 1;
+}
+
+}  // namespace mmnn

@@ -1,0 +1,409 @@
+// Implicit-GEMM "forward-shaped" convolution on fp32 MFMA for NCDHW tensors (stride 1, "same" padding).
+//
+//     out[n][m][v] = sum_{c < Cin} sum_{tap < TAPS}  w[(c*TAPS + tap)][m] * f(in[n][c][v + off(tap)])
+//
+// TAPS = 1 (1x1x1) or 27 (3x3x3).  One kernel template serves four reference ops (models/densenet.py:76-82 and
+// their autograd adjoints, main.py:469):
+//   conv1 forward   : f = ReLU(BN(x))        (PRO_BNRELU)  epilogue: store + batch statistics      (EPI_STORE_STATS)
+//   conv2 forward   : same, 27 taps, zero padding applied AFTER BN+ReLU
+//   conv2 data-grad : f = BN-backward(G, Y)   (PRO_GRAD)    epilogue: ReLU mask, dgamma/dbeta sums  (EPI_MASK_STORE)
+//   conv1 data-grad : f = BN-backward(dZ, T)  (PRO_GRAD)    epilogue: ReLU mask, G += gamma*z, sums (EPI_MASK_ACCUM)
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32): A = weights (i = output row m, k = input channel parity), B = activations
+// (k = channel parity, j = voxel), so the 32 lanes of a half read 32 CONSECUTIVE voxels of one channel from LDS
+// (conflict-free ds_read_b32) and the accumulator tile comes out as rows = m, lanes = voxels: every store
+// instruction writes 128-byte runs of one output channel.  Lanes 0-31 take channel 2k, lanes 32-63 channel 2k+1.
+#pragma once
+#include "common.hpp"
+
+namespace mmnn {
+
+enum Pro { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GRAD = 2 };
+enum Epi { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_MASK_STORE = 2, EPI_MASK_ACCUM = 3 };
+
+struct FpropArgs {
+  int N, D, H, W;
+  int Cin, M;
+  const float* in0; long in0_ns; int in0_coff;   // in0[n*in0_ns + (in0_coff + c)*V + v]
+  const float* in1; long in1_ns; int in1_coff;   // PRO_GRAD: the normalised tensor (in0 is its upstream G)
+  BnFwd bn_in;
+  BnBwd gr_in;
+  DropCfg drop_in;
+  const float* w; int w_ld;                      // w[(c*TAPS + tap)*w_ld + m]
+  float* out; long out_ns; int out_coff;
+  DropCfg drop_out;
+  StatPtr st_out;
+  const float* ex; long ex_ns; int ex_coff;
+  BnFwd ebn;
+  double* dgamma; double* dbeta;                 // [NREP][M]
+  StatPtr s_acc;
+};
+
+int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream);
+
+#if defined(__HIPCC__)
+
+template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
+struct FpropCfg {
+  static constexpr int NWAVES = WM * WN;
+  static constexpr int NTHREADS = NWAVES * 64;
+  static constexpr int M_B = WM * MT * 32;
+  static constexpr int V_B = WN * NT * 32;
+  static constexpr int RS = (TAPS == 27) ? TW + 8 : TW;
+  static constexpr int HS = (TAPS == 27) ? TH + 2 : 1;
+  static constexpr int DS = (TAPS == 27) ? TD + 2 : 1;
+  static constexpr int XS = DS * HS * RS;
+  static constexpr int NCOEF = (PRO == PRO_BNRELU) ? 2 : (PRO == PRO_GRAD ? 3 : 0);
+  static constexpr int ECOEF = 8;   // per output row: a, b, mean, rstd, gamma, dropscale, red0, red1
+  static_assert(TD * TH * TW == V_B, "tile volume must equal the block's voxel count");
+  static_assert(KC % 2 == 0, "channel chunk must be even (two channels per MFMA)");
+  static size_t smem_bytes(int Cin) {
+    int cpad = ((Cin + KC - 1) / KC) * KC;
+    size_t ncoef = ((size_t)NCOEF * cpad + 3) & ~(size_t)3;   // keep the staging buffers 16-byte aligned
+    return sizeof(float) * (ncoef + (size_t)KC * XS + (size_t)KC * TAPS * M_B + (size_t)ECOEF * M_B);
+  }
+};
+
+template <int PRO>
+__device__ __forceinline__ float pro_apply(const float* coef, int cpad, int c, float x0, float x1) {
+  if (PRO == PRO_BNRELU) return fmaxf(fmaf(coef[c], x0, coef[cpad + c]), 0.f);
+  if (PRO == PRO_GRAD) return fmaf(coef[c], x0, fmaf(coef[cpad + c], x1, coef[2 * cpad + c]));
+  return x0;
+}
+
+template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
+__global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
+  constexpr int NTHREADS = C::NTHREADS, M_B = C::M_B, V_B = C::V_B, RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int V = a.D * a.H * a.W;
+  const int cpad = ((a.Cin + KC - 1) / KC) * KC;
+
+  float* coef = smem;
+  float* Xs = coef + ((C::NCOEF * cpad + 3) & ~3);
+  float* Ws = Xs + KC * XS;
+  float* ecoef = Ws + KC * TAPS * M_B;
+
+  // ---- which tile ----
+  int n, d0 = 0, h0 = 0, w0 = 0, v0 = 0;
+  {
+    int b = blockIdx.x;
+    if (TAPS == 27) {
+      const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;
+      w0 = (b % nw) * TW; b /= nw;
+      h0 = (b % nh) * TH; b /= nh;
+      d0 = (b % nd) * TD; b /= nd;
+      n = b;
+    } else {
+      const int nt = (V + V_B - 1) / V_B;
+      v0 = (b % nt) * V_B;
+      n = b / nt;
+    }
+  }
+  const int m0 = blockIdx.y * M_B;
+  const int rep = blockIdx.x & (NREP - 1);
+
+  // ---- per-channel prologue coefficients, per-row epilogue coefficients ----
+  if (PRO == PRO_BNRELU) {
+    for (int c = tid; c < cpad; c += NTHREADS) {
+      float ca = 0.f, cb = 0.f, mu, rs;
+      if (c < a.Cin) bn_fwd_coef(a.bn_in, c, ca, cb, mu, rs);
+      coef[c] = ca; coef[cpad + c] = cb;
+    }
+  } else if (PRO == PRO_GRAD) {
+    for (int c = tid; c < cpad; c += NTHREADS) {
+      float p = 0.f, q = 0.f, r = 0.f;
+      if (c < a.Cin) {
+        bn_bwd_coef(a.gr_in, c, p, q, r);
+        const float s = drop_scale(a.drop_in, n, c);
+        p *= s; q *= s; r *= s;
+      }
+      coef[c] = p; coef[cpad + c] = q; coef[2 * cpad + c] = r;
+    }
+  }
+  for (int m = tid; m < M_B; m += NTHREADS) {
+    float ea = 0.f, eb = 0.f, mu = 0.f, rs = 0.f, g = 0.f, ds = 1.f;
+    if (m0 + m < a.M) {
+      if (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) {
+        bn_fwd_coef(a.ebn, m0 + m, ea, eb, mu, rs);
+        g = a.ebn.gamma[m0 + m];
+      }
+      if (EPI == EPI_STORE_STATS) ds = drop_scale(a.drop_out, n, m0 + m);
+    }
+    ecoef[m] = ea; ecoef[M_B + m] = eb; ecoef[2 * M_B + m] = mu; ecoef[3 * M_B + m] = rs;
+    ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds; ecoef[6 * M_B + m] = 0.f; ecoef[7 * M_B + m] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- accumulators and per-lane voxel positions ----
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int pos[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = (wn * NT + j) * 32 + l31;
+    if (TAPS == 27) {
+      const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+      pos[j] = (dz * HS + hy) * RS + wx + 3;
+    } else {
+      pos[j] = t;
+    }
+  }
+
+  const float* in0n = a.in0 + (long)n * a.in0_ns + (long)a.in0_coff * V;
+  const float* in1n = (PRO == PRO_GRAD) ? a.in1 + (long)n * a.in1_ns + (long)a.in1_coff * V : nullptr;
+  const bool vecx = (TAPS == 27) ? ((a.W & 3) == 0) : ((V & 3) == 0);
+  const bool vecw = ((a.w_ld & 3) == 0) && ((a.M & 3) == 0);
+
+  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+    // ================= stage activations =================
+    if (TAPS == 27) {
+      if (vecx) {
+        constexpr int IPR = TW / 4 + 2;
+        constexpr int ITEMS = KC * DS * HS * IPR;
+        for (int it = tid; it < ITEMS; it += NTHREADS) {
+          const int q = it % IPR;
+          int row = it / IPR;
+          const int hy = row % HS; row /= HS;
+          const int dz = row % DS;
+          const int cl = row / DS;
+          const int c = c0 + cl;
+          const int d = d0 + dz - 1, h = h0 + hy - 1;
+          const bool rowok = (c < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
+          float* dst = Xs + cl * XS + (dz * HS + hy) * RS;
+          const long gro = (long)c * V + ((long)d * a.H + h) * a.W;
+          if (q < TW / 4) {
+            const int w = w0 + 4 * q;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (rowok && w < a.W) {
+              f32x4 x0 = *reinterpret_cast<const f32x4*>(in0n + gro + w);
+              f32x4 x1 = x0;
+              if (PRO == PRO_GRAD) x1 = *reinterpret_cast<const f32x4*>(in1n + gro + w);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c, x0[e], x1[e]);
+            }
+            *reinterpret_cast<f32x4*>(dst + 4 + 4 * q) = o;
+          } else {
+            const int w = (q == TW / 4) ? w0 - 1 : w0 + TW;
+            float o = 0.f;
+            if (rowok && (unsigned)w < (unsigned)a.W) {
+              const float x0 = in0n[gro + w];
+              const float x1 = (PRO == PRO_GRAD) ? in1n[gro + w] : x0;
+              o = pro_apply<PRO>(coef, cpad, c, x0, x1);
+            }
+            dst[(q == TW / 4) ? 3 : TW + 4] = o;
+          }
+        }
+      } else {
+        constexpr int IPR = TW + 2;
+        constexpr int ITEMS = KC * DS * HS * IPR;
+        for (int it = tid; it < ITEMS; it += NTHREADS) {
+          const int q = it % IPR;
+          int row = it / IPR;
+          const int hy = row % HS; row /= HS;
+          const int dz = row % DS;
+          const int cl = row / DS;
+          const int c = c0 + cl;
+          const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + q - 1;
+          float o = 0.f;
+          if ((c < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) {
+            const long g = (long)c * V + ((long)d * a.H + h) * a.W + w;
+            const float x0 = in0n[g];
+            const float x1 = (PRO == PRO_GRAD) ? in1n[g] : x0;
+            o = pro_apply<PRO>(coef, cpad, c, x0, x1);
+          }
+          Xs[cl * XS + (dz * HS + hy) * RS + 3 + q] = o;
+        }
+      }
+    } else {
+      if (vecx) {
+        constexpr int ITEMS = KC * V_B / 4;
+        for (int it = tid; it < ITEMS; it += NTHREADS) {
+          const int q = it % (V_B / 4);
+          const int cl = it / (V_B / 4);
+          const int c = c0 + cl;
+          const int v = v0 + 4 * q;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (c < a.Cin && v < V) {
+            const long g = (long)c * V + v;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(in0n + g);
+            f32x4 x1 = x0;
+            if (PRO == PRO_GRAD) x1 = *reinterpret_cast<const f32x4*>(in1n + g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c, x0[e], x1[e]);
+          }
+          *reinterpret_cast<f32x4*>(Xs + cl * XS + 4 * q) = o;
+        }
+      } else {
+        constexpr int ITEMS = KC * V_B;
+        for (int it = tid; it < ITEMS; it += NTHREADS) {
+          const int q = it % V_B;
+          const int cl = it / V_B;
+          const int c = c0 + cl;
+          const int v = v0 + q;
+          float o = 0.f;
+          if (c < a.Cin && v < V) {
+            const long g = (long)c * V + v;
+            const float x0 = in0n[g];
+            const float x1 = (PRO == PRO_GRAD) ? in1n[g] : x0;
+            o = pro_apply<PRO>(coef, cpad, c, x0, x1);
+          }
+          Xs[cl * XS + q] = o;
+        }
+      }
+    }
+    // ================= stage weights =================
+    {
+      const int krows = KC * TAPS;
+      const long kbase = (long)c0 * TAPS;
+      const long klim = (long)a.Cin * TAPS;
+      if (vecw) {
+        const int items = krows * (M_B / 4);
+        for (int it = tid; it < items; it += NTHREADS) {
+          const int q = it % (M_B / 4);
+          const int kr = it / (M_B / 4);
+          const int m = m0 + 4 * q;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (kbase + kr < klim && m < a.M) o = *reinterpret_cast<const f32x4*>(a.w + (kbase + kr) * a.w_ld + m);
+          *reinterpret_cast<f32x4*>(Ws + kr * M_B + 4 * q) = o;
+        }
+      } else {
+        const int items = krows * M_B;
+        for (int it = tid; it < items; it += NTHREADS) {
+          const int q = it % M_B;
+          const int kr = it / M_B;
+          float o = 0.f;
+          if (kbase + kr < klim && m0 + q < a.M) o = a.w[(kbase + kr) * a.w_ld + m0 + q];
+          Ws[kr * M_B + q] = o;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= MFMA over the chunk =================
+    {
+      const float* xb = Xs + half * XS;
+      const float* wb = Ws + half * TAPS * M_B + wm * MT * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int toff = (TAPS == 27) ? (((tap / 9) * HS + (tap / 3) % 3) * RS + tap % 3) : 0;
+          float av[MT], bv[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) av[i] = wb[(2 * kk * TAPS + tap) * M_B + i * 32];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bv[j] = xb[2 * kk * XS + pos[j] + toff];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ================= epilogue =================
+  float* red0 = ecoef + 6 * M_B;
+  float* red1 = ecoef + 7 * M_B;
+  float* outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
+  const float* exn = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) ? a.ex + (long)n * a.ex_ns + (long)a.ex_coff * V : nullptr;
+  const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
+
+  long vox[NT];
+  bool vok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = (wn * NT + j) * 32 + l31;
+    if (TAPS == 27) {
+      const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+      const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+      vok[j] = d < a.D && h < a.H && w < a.W;
+      vox[j] = ((long)d * a.H + h) * a.W + w;
+    } else {
+      vox[j] = v0 + t;
+      vok[j] = vox[j] < V;
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float s0[16], s1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * MT * 32 + i * 32 + acc_row(r, half);
+      const bool mok = (m0 + ml) < a.M;
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool ok = mok && vok[j];
+        const long o = (long)(m0 + ml) * V + vox[j];
+        float val = acc[i][j][r];
+        if (EPI == EPI_STORE) {
+          if (ok) outn[o] = val;
+        } else if (EPI == EPI_STORE_STATS) {
+          val *= ecoef[5 * M_B + ml];
+          if (ok) {
+            outn[o] = val;
+            t0 += val;
+            t1 += val * val;
+          }
+        } else {
+          if (ok) {
+            const float x = exn[o];
+            const float pre = fmaf(ecoef[ml], x, ecoef[M_B + ml]);
+            const float z = pre > 0.f ? val : 0.f;
+            const float xh = (x - ecoef[2 * M_B + ml]) * ecoef[3 * M_B + ml];
+            t0 += z;
+            t1 += z * xh;
+            if (EPI == EPI_MASK_STORE) outn[o] = z;
+            else outn[o] += ecoef[4 * M_B + ml] * z;
+          }
+        }
+      }
+      s0[r] = t0;
+      s1[r] = t1;
+    }
+    if (want_sums) {
+      const float r0 = half_reduce16(s0, lane);
+      const float r1 = half_reduce16(s1, lane);
+      if ((lane & 1) == 0) {
+        const int ml = wm * MT * 32 + i * 32 + acc_row((l31 >> 1) & 15, half);
+        atomicAdd(&red0[ml], r0);
+        atomicAdd(&red1[ml], r1);
+      }
+    }
+  }
+  if (want_sums) {
+    __syncthreads();
+    for (int m = tid; m < M_B; m += NTHREADS) {
+      if (m0 + m >= a.M) continue;
+      const double v0d = (double)red0[m], v1d = (double)red1[m];
+      if (EPI == EPI_STORE_STATS) {
+        atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + m0 + m, v0d);
+        atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + m0 + m, v1d);
+      } else {
+        atomicAdd(a.dbeta + (long)rep * a.M + m0 + m, v0d);
+        atomicAdd(a.dgamma + (long)rep * a.M + m0 + m, v1d);
+        if (EPI == EPI_MASK_ACCUM) {
+          const double g = (double)ecoef[4 * M_B + m];
+          atomicAdd(a.s_acc.sum + (long)rep * a.s_acc.stride + a.s_acc.off + m0 + m, g * v0d);
+          atomicAdd(a.s_acc.sq + (long)rep * a.s_acc.stride + a.s_acc.off + m0 + m, g * v1d);
+        }
+      }
+    }
+  }
+}
+
+#endif  // __HIPCC__
+}  // namespace mmnn

@@ -1,0 +1,406 @@
+// Stem kernels: conv0 (7x7x7, stride 2) forward on fp32 MFMA, BN+ReLU+max-pool forward/backward, conv0 weight
+// gradient on fp32 MFMA.  Reference: models/densenet.py:199-202 and their autograd adjoints (main.py:469).
+#include "stem.hpp"
+
+namespace mmnn {
+
+// =====================================================================================================================
+// conv0 forward.  Implicit GEMM: i = output channel (2 tiles of 32), j = 32 consecutive output voxels along W,
+// k = two taps per MFMA.  One block = output tile 2 x 4 x 32; loop over kd, staging per kd the two needed input
+// planes (W de-interleaved by parity so that the stride-2 gather of a tap is a contiguous, conflict-free LDS read)
+// and the 49 (kh,kw) weight rows.  Lane halves take channel 2k / 2k+1 (even Cin) or taps kw / kw+1 (odd Cin).
+// =====================================================================================================================
+constexpr int SC_TD = 2, SC_TH = 4, SC_TW = 32;
+constexpr int SC_ROWS = 2 * SC_TH + 5;     // 13 input rows
+constexpr int SC_PO = 36;                  // parity plane stride (>= 35 entries used)
+constexpr int SC_RS = 2 * SC_PO;           // 72
+constexpr int SC_CS = SC_TD * SC_ROWS * SC_RS;
+constexpr int SC_MAXC = 4;
+
+template <bool PAIR_C>
+__global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int krows = PAIR_C ? a.Cin * 49 : a.Cin * 56;
+  float* Xs = smem;                           // [Cin][2][13][72]
+  float* Ws = Xs + a.Cin * SC_CS;             // [krows][64]
+  float* red = Ws + krows * 64;               // [2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int Vi = a.D * a.H * a.W, Vo = a.Do * a.Ho * a.Wo;
+  int b = blockIdx.x;
+  const int nw = (a.Wo + SC_TW - 1) / SC_TW, nh = (a.Ho + SC_TH - 1) / SC_TH, nd = (a.Do + SC_TD - 1) / SC_TD;
+  const int wo0 = (b % nw) * SC_TW; b /= nw;
+  const int ho0 = (b % nh) * SC_TH; b /= nh;
+  const int do0 = (b % nd) * SC_TD; b /= nd;
+  const int n = b;
+  const int rep = blockIdx.x & (NREP - 1);
+  if (tid < 128) red[tid] = 0.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int pos[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jt = wave * 2 + j;
+    pos[j] = ((jt / SC_TH) * SC_ROWS + 2 * (jt % SC_TH)) * SC_RS + l31;
+  }
+  const float* xn = a.x + (long)n * a.Cin * Vi;
+
+  for (int kd = 0; kd < 7; ++kd) {
+    __syncthreads();
+    // ---- stage input planes d_in = 2*(do0+dz) + kd - 3 ----
+    const int items = a.Cin * SC_TD * SC_ROWS * 69;
+    for (int it = tid; it < items; it += 256) {
+      const int ci = it % 69;
+      int row = it / 69;
+      const int r = row % SC_ROWS; row /= SC_ROWS;
+      const int dz = row % SC_TD;
+      const int c = row / SC_TD;
+      const int d = 2 * (do0 + dz) + kd - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
+      float v = 0.f;
+      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = xn[(long)c * Vi + ((long)d * a.H + h) * a.W + w];
+      Xs[c * SC_CS + (dz * SC_ROWS + r) * SC_RS + (ci & 1) * SC_PO + (ci >> 1)] = v;
+    }
+    // ---- stage this kd's weight rows ----
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wp + (long)kd * krows * 64);
+    for (int it = tid; it < krows * 16; it += 256) reinterpret_cast<f32x4*>(Ws)[it] = wsrc[it];
+    __syncthreads();
+
+    if (PAIR_C) {
+      for (int cp = 0; cp < a.Cin / 2; ++cp) {
+        const float* xb = Xs + (2 * cp + half) * SC_CS;
+        const float* wb = Ws + (2 * cp + half) * 49 * 64 + l31;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+          for (int kw = 0; kw < 7; ++kw) {
+            const int toff = kh * SC_RS + (kw & 1) * SC_PO + (kw >> 1);
+            const float a0 = wb[(kh * 7 + kw) * 64], a1 = wb[(kh * 7 + kw) * 64 + 32];
+            const float b0 = xb[pos[0] + toff], b1 = xb[pos[1] + toff];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      for (int c = 0; c < a.Cin; ++c) {
+        const float* xb = Xs + c * SC_CS + half * SC_PO;
+        const float* wb = Ws + (c * 56 + half) * 64 + l31;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+          for (int kp = 0; kp < 4; ++kp) {
+            const int toff = kh * SC_RS + kp;
+            const float a0 = wb[(kh * 8 + 2 * kp) * 64], a1 = wb[(kh * 8 + 2 * kp) * 64 + 32];
+            const float b0 = xb[pos[0] + toff], b1 = xb[pos[1] + toff];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: store + batch statistics ----
+  float* outn = a.out + (long)n * a.M * Vo;
+  long vox[2];
+  bool vok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jt = wave * 2 + j;
+    const int d = do0 + jt / SC_TH, h = ho0 + jt % SC_TH, w = wo0 + l31;
+    vok[j] = d < a.Do && h < a.Ho && w < a.Wo;
+    vox[j] = ((long)d * a.Ho + h) * a.Wo + w;
+  }
+  const bool want = a.st_out.sum != nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s0[16], s1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = i * 32 + acc_row(r, half);
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (m < a.M && vok[j]) {
+          const float v = acc[i][j][r];
+          outn[(long)m * Vo + vox[j]] = v;
+          t0 += v;
+          t1 += v * v;
+        }
+      }
+      s0[r] = t0; s1[r] = t1;
+    }
+    if (want) {
+      const float r0 = half_reduce16(s0, lane), r1 = half_reduce16(s1, lane);
+      if ((lane & 1) == 0) {
+        const int m = i * 32 + acc_row((l31 >> 1) & 15, half);
+        atomicAdd(&red[m], r0);
+        atomicAdd(&red[64 + m], r1);
+      }
+    }
+  }
+  if (want) {
+    __syncthreads();
+    if (tid < a.M) {
+      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + tid, (double)red[tid]);
+      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + tid, (double)red[64 + tid]);
+    }
+  }
+}
+
+int launch_stem_conv(const StemConvArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cin <= SC_MAXC, "stem conv: in_channels %d outside [1,%d]", a.Cin, SC_MAXC);
+  MMNN_REQUIRE(a.M > 0 && a.M <= 64, "stem conv: init_features %d outside [1,64]", a.M);
+  MMNN_REQUIRE(a.Do == (a.D - 1) / 2 + 1 && a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1, "stem conv: output extent mismatch");
+  MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "stem conv: volume too large");
+  const int krows = stem_krows(a.Cin);
+  const size_t smem = sizeof(float) * ((size_t)a.Cin * SC_CS + (size_t)krows * 64 + 128);
+  const long blocks = (long)a.N * cdiv(a.Do, SC_TD) * cdiv(a.Ho, SC_TH) * cdiv(a.Wo, SC_TW);
+  MMNN_REQUIRE(blocks < (1l << 31) && smem <= 160 * 1024, "stem conv: launch out of range");
+  const bool pair_c = (a.Cin % 2 == 0);
+  auto kern = pair_c ? stem_conv_kernel<true> : stem_conv_kernel<false>;
+  MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================================
+// BN + ReLU + max-pool(3, stride 2, pad 1) forward; records the winning tap for the backward pass.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Vi = a.Di * a.Hi * a.Wi, Vo = a.Do * a.Ho * a.Wo;
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float* xc = a.x + ((long)n * a.C + c) * Vi;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  float best = 0.f, s0 = 0.f, s1 = 0.f;
+  if (p < Vo) {
+    const int wo = p % a.Wo, ho = (p / a.Wo) % a.Ho, d_o = p / (a.Wo * a.Ho);
+    best = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int d = 2 * d_o - 1 + kd;
+      if ((unsigned)d >= (unsigned)a.Di) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * ho - 1 + kh;
+        if ((unsigned)h >= (unsigned)a.Hi) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int w = 2 * wo - 1 + kw;
+          if ((unsigned)w >= (unsigned)a.Wi) continue;
+          const float v = fmaxf(fmaf(ca, xc[((long)d * a.Hi + h) * a.Wi + w], cb), 0.f);
+          if (v > best) { best = v; bi = kd * 9 + kh * 3 + kw; }
+        }
+      }
+    }
+    a.out[(long)n * a.out_ns + (long)c * Vo + p] = best;
+    a.idx[((long)n * a.C + c) * Vo + p] = (unsigned char)bi;
+    s0 = best; s1 = best * best;
+  }
+  if (a.st_out.sum) {
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int rep = blockIdx.x & (NREP - 1);
+      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + c, (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + c, (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+  }
+}
+
+int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "stem pool: bad extent");
+  MMNN_REQUIRE(a.Do == (a.Di - 1) / 2 + 1 && a.Ho == (a.Hi - 1) / 2 + 1 && a.Wo == (a.Wi - 1) / 2 + 1, "stem pool: output extent mismatch");
+  const int Vo = a.Do * a.Ho * a.Wo;
+  hipLaunchKernelGGL(stem_pool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================================
+// Backward of BN+ReLU+max-pool:  dz[q] = relu'(q) * sum over windows p whose argmax is q of dP[p],
+// dP = BN-backward(G, pooled) on the fly;  also dgamma0 / dbeta0 sums.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArgs a) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Vi = a.Di * a.Hi * a.Wi, Vo = a.Do * a.Ho * a.Wo;
+  float ca, cb, mu, rs, gp, gq, gr;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  bn_bwd_coef(a.gr, c, gp, gq, gr);
+  const float* xc = a.x + ((long)n * a.C + c) * Vi;
+  const float* gc = a.g + (long)n * a.g_ns + (long)c * Vo;
+  const float* pc = a.xp + (long)n * a.xp_ns + (long)c * Vo;
+  const unsigned char* ic = a.idx + ((long)n * a.C + c) * Vo;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  if (q < Vi) {
+    const int w = q % a.Wi, h = (q / a.Wi) % a.Hi, d = q / (a.Wi * a.Hi);
+    const float x = xc[q];
+    float z = 0.f;
+    if (fmaf(ca, x, cb) > 0.f) {
+      // windows p with 2p-1+k = q, k in {0,1,2}:  q even -> k=1;  q odd -> k=0 (p=(q+1)/2) and k=2 (p=(q-1)/2)
+      int pd[2], kdv[2], nd = 0, ph[2], khv[2], nh = 0, pw[2], kwv[2], nw = 0;
+      if (d & 1) { if ((d + 1) / 2 < a.Do) { pd[nd] = (d + 1) / 2; kdv[nd++] = 0; } pd[nd] = (d - 1) / 2; kdv[nd++] = 2; }
+      else if (d / 2 < a.Do) { pd[nd] = d / 2; kdv[nd++] = 1; }
+      if (h & 1) { if ((h + 1) / 2 < a.Ho) { ph[nh] = (h + 1) / 2; khv[nh++] = 0; } ph[nh] = (h - 1) / 2; khv[nh++] = 2; }
+      else if (h / 2 < a.Ho) { ph[nh] = h / 2; khv[nh++] = 1; }
+      if (w & 1) { if ((w + 1) / 2 < a.Wo) { pw[nw] = (w + 1) / 2; kwv[nw++] = 0; } pw[nw] = (w - 1) / 2; kwv[nw++] = 2; }
+      else if (w / 2 < a.Wo) { pw[nw] = w / 2; kwv[nw++] = 1; }
+      for (int i = 0; i < nd; ++i)
+        for (int j = 0; j < nh; ++j)
+          for (int k = 0; k < nw; ++k) {
+            if (pd[i] >= a.Do || ph[j] >= a.Ho || pw[k] >= a.Wo) continue;
+            const long p = ((long)pd[i] * a.Ho + ph[j]) * a.Wo + pw[k];
+            if (ic[p] == kdv[i] * 9 + khv[j] * 3 + kwv[k]) z += fmaf(gp, gc[p], fmaf(gq, pc[p], gr));
+          }
+    }
+    a.dz[((long)n * a.C + c) * Vi + q] = z;
+    s0 = z; s1 = z * (x - mu) * rs;
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int rep = blockIdx.x & (NREP - 1);
+    atomicAdd(a.dbeta + (long)rep * a.C + c, (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(a.dgamma + (long)rep * a.C + c, (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+int launch_stem_pool_bwd(const StemPoolBwdArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "stem pool bwd: bad extent");
+  const int Vi = a.Di * a.Hi * a.Wi;
+  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(cdiv(Vi, 256), a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================================
+// conv0 weight gradient.  i = output channel (2 tiles), j = 32 taps of the flattened (kd,kh,kw) index, k = output
+// voxel.  11 waves per block (11 x 32 = 352 >= 343 taps), one input channel per block (blockIdx.y), tile of
+// 2 x 2 x 16 output voxels; the input halo is staged with row stride == 7 and plane stride == 17 (mod 32) so that
+// the 32 taps of a wave (LDS offset == tap index mod 32) fall in 32 different banks.
+// =====================================================================================================================
+constexpr int SW_TD = 2, SW_TH = 2, SW_TW = 16;
+constexpr int SW_RS = 39;                                // >= 2*16+5 = 37, == 7 (mod 32)
+constexpr int SW_ROWS = 2 * SW_TH + 5;                   // 9
+constexpr int SW_PS = 369;                               // >= 9*39 = 351, == 17 (mod 32)
+constexpr int SW_PLANES = 2 * SW_TD + 5;                 // 9
+constexpr int SW_XN = SW_PLANES * SW_PS;
+constexpr int SW_YS = 65;
+constexpr int SW_THREADS = 11 * 64;
+
+__global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradArgs a) {
+  __shared__ float Xs[SW_XN];
+  __shared__ float Ys[64 * SW_YS];
+  __shared__ float gcoef[3 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int Vi = a.D * a.H * a.W, Vo = a.Do * a.Ho * a.Wo;
+  const int split = blockIdx.x, c = blockIdx.y;
+  const int nw = (a.Wo + SW_TW - 1) / SW_TW, nh = (a.Ho + SW_TH - 1) / SW_TH, nd = (a.Do + SW_TD - 1) / SW_TD;
+  const int ntiles = a.N * nw * nh * nd;
+  const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
+  if (tid < 64) {
+    float p = 0.f, q = 0.f, r = 0.f;
+    if (tid < a.M) bn_bwd_coef(a.gr, tid, p, q, r);
+    gcoef[tid] = p; gcoef[64 + tid] = q; gcoef[128 + tid] = r;
+  }
+  const int tap = wave * 32 + l31;                       // >= 343: padding lanes (results discarded)
+  const int tkd = tap / 49, tkh = (tap / 7) % 7, tkw = tap % 7;
+  const int tapoff = (tap < 343) ? tkd * SW_PS + tkh * SW_RS + tkw : 0;
+  const float* xl = Xs + tapoff + half * (2 * SW_PS);    // voxel s+32 is one output depth slice further
+  const float* yl = Ys + l31 * SW_YS + 32 * half;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b = tile;
+    const int wo0 = (b % nw) * SW_TW; b /= nw;
+    const int ho0 = (b % nh) * SW_TH; b /= nh;
+    const int do0 = (b % nd) * SW_TD; b /= nd;
+    const int n = b;
+    const float* xc = a.x + ((long)n * a.Cin + c) * Vi;
+    __syncthreads();
+#pragma unroll 4
+    for (int it = tid; it < SW_PLANES * SW_ROWS * 37; it += SW_THREADS) {
+      const int ci = it % 37;
+      const int r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
+      const int d = 2 * do0 + pl - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
+      float v = 0.f;
+      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = xc[((long)d * a.H + h) * a.W + w];
+      Xs[pl * SW_PS + r * SW_RS + ci] = v;
+    }
+#pragma unroll 2
+    for (int it = tid; it < 64 * 64; it += SW_THREADS) {
+      const int t = it & 63, m = it >> 6;
+      const int wx = t % SW_TW, hy = (t / SW_TW) % SW_TH, dz = t / (SW_TW * SW_TH);
+      const int d = do0 + dz, h = ho0 + hy, w = wo0 + wx;
+      float o = 0.f;
+      if (m < a.M && d < a.Do && h < a.Ho && w < a.Wo) {
+        const long g = ((long)n * a.M + m) * Vo + ((long)d * a.Ho + h) * a.Wo + w;
+        o = fmaf(gcoef[m], a.dz[g], fmaf(gcoef[64 + m], a.y[g], gcoef[128 + m]));
+      }
+      Ys[m * SW_YS + t] = o;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s0 = 0; s0 < 32; s0 += 8) {
+      const float* xg = xl + (2 * (s0 / SW_TW)) * SW_RS + 2 * (s0 % SW_TW);   // s < 32: dz = 0, hy = s/16, wx = s%16
+      const float* yg = yl + s0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float bv = xg[2 * i];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yg[i], bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yg[32 * SW_YS + i], bv, acc[1], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.slab + (long)split * a.slab_stride + (long)c * a.M * 352;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = t * 32 + acc_row(r, half);
+      if (m < a.M) out[(long)m * 352 + tap] = acc[t][r];
+    }
+}
+
+int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo) {
+  const long ntiles = (long)N * cdiv(Do, SW_TD) * cdiv(Ho, SW_TH) * cdiv(Wo, SW_TW);
+  long s = 128;
+  if (s > ntiles / 2) s = ntiles / 2;
+  return s < 1 ? 1 : (int)s;
+}
+
+int launch_stem_wgrad(const StemWgradArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cin <= 65535 && a.M > 0 && a.M <= 64, "stem wgrad: bad extent");
+  MMNN_REQUIRE(a.nsplit >= 1 && a.slab_stride >= (long)a.Cin * a.M * 352, "stem wgrad: bad slab layout");
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(a.nsplit, a.Cin), dim3(SW_THREADS), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmnn

@@ -1,0 +1,94 @@
+// Host-side dispatch of the weight-gradient kernels (wgrad.hpp).
+#include "wgrad.hpp"
+
+namespace mmnn {
+
+static void wg3_tile(int W, int& TD, int& TH, int& TW) {
+  if (W > 16) { TD = 1; TH = 2; TW = 32; }
+  else if (W > 8) { TD = 1; TH = 4; TW = 16; }
+  else if (W > 4) { TD = 2; TH = 4; TW = 8; }
+  else { TD = 4; TH = 4; TW = 4; }
+}
+
+static int wg1_wc(int Cin) { return Cin >= 256 ? 8 : (Cin >= 128 ? 4 : 2); }
+
+int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
+  if (taps == 27) {
+    int TD, TH, TW;
+    wg3_tile(W, TD, TH, TW);
+    const long ntiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+    const int cgroups = cdiv(Cin, 32);
+    long s = 512 / cgroups;
+    if (s > 64) s = 64;
+    if (s > ntiles / 2) s = ntiles / 2;
+    return s < 1 ? 1 : (int)s;
+  }
+  const long V = (long)D * H * W;
+  const long nchunks = (long)N * cdiv(V, 64);
+  const int wc = wg1_wc(Cin);
+  const long waves_per_split = (long)cdiv(Cin, 32 * wc) * wc * cdiv(M, 128);
+  long s = 2048 / waves_per_split;
+  if (s > 64) s = 64;
+  if (s > nchunks / 2) s = nchunks / 2;
+  return s < 1 ? 1 : (int)s;
+}
+
+template <int PRO_X, int TD, int TH, int TW>
+static int launch3(const WgradArgs& a, hipStream_t stream) {
+  using C = Wg3Cfg<TD, TH, TW>;
+  auto kern = wgrad3_kernel<PRO_X, TD, TH, TW>;
+  const size_t smem = C::smem_bytes();
+  static bool configured = false;
+  if (!configured) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nsplit, cdiv(a.Cin, 32)), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int PRO_X, int WC>
+static int launch1(const WgradArgs& a, hipStream_t stream) {
+  using C = Wg1Cfg<WC>;
+  auto kern = wgrad1_kernel<PRO_X, WC>;
+  const size_t smem = C::smem_bytes();
+  static bool configured = false;
+  if (!configured) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int PRO_X>
+static int dispatch(const WgradArgs& a, int taps, hipStream_t s) {
+  if (taps == 27) {
+    if (a.W > 16) return launch3<PRO_X, 1, 2, 32>(a, s);
+    if (a.W > 8) return launch3<PRO_X, 1, 4, 16>(a, s);
+    if (a.W > 4) return launch3<PRO_X, 2, 4, 8>(a, s);
+    return launch3<PRO_X, 4, 4, 4>(a, s);
+  }
+  const int wc = wg1_wc(a.Cin);
+  if (wc == 8) return launch1<PRO_X, 8>(a, s);
+  if (wc == 4) return launch1<PRO_X, 4>(a, s);
+  return launch1<PRO_X, 2>(a, s);
+}
+
+int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "wgrad: non-positive extent");
+  MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "wgrad: volume too large for 32-bit voxel indices");
+  MMNN_REQUIRE(a.g0 && a.g1 && a.x && a.slab, "wgrad: null operand");
+  MMNN_REQUIRE(a.nsplit >= 1 && a.nsplit <= 65535, "wgrad: bad split count %d", a.nsplit);
+  MMNN_REQUIRE(taps == 1 || taps == 27, "wgrad: taps must be 1 or 27");
+  MMNN_REQUIRE(taps != 27 || a.M <= 32, "wgrad: the 3x3x3 kernel handles at most 32 output channels (growth rate), got %d", a.M);
+  MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");
+  if (pro_x == PRO_BNRELU) return dispatch<PRO_BNRELU>(a, taps, stream);
+  if (pro_x == PRO_NONE) return dispatch<PRO_NONE>(a, taps, stream);
+  set_error("wgrad: unsupported input prologue %d", pro_x);
+  return 1;
+}
+
+}  // namespace mmnn

@@ -1,0 +1,308 @@
+// Weight-gradient kernels (autograd adjoint of the dense-layer convolutions wrt their weights, main.py:469 ->
+// models/densenet.py:78,82,147) on fp32 MFMA, split over the voxel (reduction) axis into deterministic partial slabs.
+//
+//     dW[m][c][tap] = sum_{n,v}  dOut[n][m][v] * f(in[n][c][v + off(tap)])
+//
+// with dOut = BN-backward(G, X) evaluated on the fly (PRO_GRAD) and f = ReLU(BN(.)) (PRO_BNRELU) or identity.
+// MFMA mapping: i = output channel m, j = input channel c, k = voxel.  Both operands are staged channel-major in LDS
+// with an ODD row stride, so the 32 lanes of a half (32 different channels, same voxel) hit 32 different banks.
+// Lanes 0-31 take voxel s of the tile, lanes 32-63 voxel s+32.
+//
+// Every block owns one (split, channel-group) pair, walks its share of spatial tiles and stores its partial result to
+// slab[split]; slabs are summed by the gradient finaliser (finalize.hip) -- no float atomics, bit-reproducible.
+#pragma once
+#include "common.hpp"
+#include "fprop.hpp"
+
+namespace mmnn {
+
+struct WgradArgs {
+  int N, D, H, W;
+  int M, Cin;
+  // dOut operand: G (in g0) and the normalised tensor (in g1), BN-backward coefficients, channel dropout
+  const float* g0; long g0_ns; int g0_coff;
+  const float* g1; long g1_ns; int g1_coff;
+  BnBwd gr;
+  DropCfg drop;
+  // input operand
+  const float* x; long x_ns; int x_coff;
+  BnFwd bn;                                   // PRO_BNRELU (ignored for PRO_NONE)
+  // output slabs: 1x1: slab[split][m][c]   3x3x3: slab[split][tap][m][c]
+  float* slab; long slab_stride; int nsplit;
+};
+
+int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream);
+int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin);
+
+#if defined(__HIPCC__)
+
+// ----------------------------------------------------------------------------------------------------------------
+// 3x3x3:  block = 9 waves (one (kd,kh) pair each, 3 accumulator tiles for kw = 0..2), one 32-channel group of c.
+// ----------------------------------------------------------------------------------------------------------------
+template <int TD, int TH, int TW>
+struct Wg3Cfg {
+  static constexpr int VT = TD * TH * TW;            // 64 voxels per tile
+  static constexpr int RS = TW + 2, HS = TH + 2, DS = TD + 2;
+  static constexpr int XS = (DS * HS * RS) | 1;      // odd channel stride
+  static constexpr int YS = VT + 1;
+  static constexpr int NTHREADS = 9 * 64;
+  static_assert(VT == 64, "tile must hold 64 voxels (two per MFMA k-step, 32 steps)");
+  static_assert(32 % TW == 0, "tile width must divide 32");
+  static size_t smem_bytes() { return sizeof(float) * (32 * XS + 32 * YS + 3 * 32 + 2 * 32 + 3 * 32); }
+};
+
+template <int PRO_X, int TD, int TH, int TW>
+__global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
+  using C = Wg3Cfg<TD, TH, TW>;
+  constexpr int RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS, YS = C::YS, NTHREADS = C::NTHREADS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                 // [32 c][XS]
+  float* Ys = Xs + 32 * XS;         // [32 m][YS]
+  float* gcoef = Ys + 32 * YS;      // p,q,r for the 32 rows of dOut
+  float* xcoef = gcoef + 96;        // a,b for the 32 input channels
+  float* gbase = xcoef + 64;        // p,q,r before the per-sample dropout scale
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int V = a.D * a.H * a.W;
+  const int split = blockIdx.x, cg = blockIdx.y;
+  const int c0 = cg * 32;
+  const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;
+  const int tiles_per_n = nw * nh * nd;
+  const int ntiles = a.N * tiles_per_n;
+  const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
+
+  if (tid < 32) {
+    float ca = 0.f, cb = 0.f, mu, rs;
+    if (PRO_X == PRO_BNRELU && c0 + tid < a.Cin) bn_fwd_coef(a.bn, c0 + tid, ca, cb, mu, rs);
+    xcoef[tid] = ca; xcoef[32 + tid] = cb;
+    float p = 0.f, q = 0.f, r = 0.f;
+    if (tid < a.M) bn_bwd_coef(a.gr, tid, p, q, r);
+    gbase[tid] = p; gbase[32 + tid] = q; gbase[64 + tid] = r;
+  }
+  const int kd = wave / 3, kh = wave % 3;
+  // lane-half offset: voxel (s + 32*half) = voxel s shifted by 32/TW rows
+  constexpr int ROWS_PER_HALF = 32 / TW;
+  const int hrow = half * ROWS_PER_HALF;
+  const int hoff = ((hrow / TH) * HS + (hrow % TH)) * RS;
+  const float* xl = Xs + l31 * XS + hoff + (kd * HS + kh) * RS;
+  const float* yl = Ys + l31 * YS + 32 * half;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int cur_n = -1;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b = tile;
+    const int w0 = (b % nw) * TW; b /= nw;
+    const int h0 = (b % nh) * TH; b /= nh;
+    const int d0 = (b % nd) * TD; b /= nd;
+    const int n = b;
+    if (n != cur_n) {   // dropout scale depends on the sample: refresh the dOut coefficients
+      __syncthreads();
+      if (tid < 32) {
+        const float s = drop_scale(a.drop, n, tid);
+        gcoef[tid] = gbase[tid] * s; gcoef[32 + tid] = gbase[32 + tid] * s; gcoef[64 + tid] = gbase[64 + tid] * s;
+      }
+      cur_n = n;
+      __syncthreads();
+    }
+    const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
+    const float* g0n = a.g0 + (long)n * a.g0_ns + (long)a.g0_coff * V;
+    const float* g1n = a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
+    // ---- stage the input halo box (zero padded AFTER the activation) ----
+    constexpr int XITEMS = 32 * DS * HS * RS;
+#pragma unroll 4
+    for (int it = tid; it < XITEMS; it += NTHREADS) {
+      const int q = it % RS;
+      int row = it / RS;
+      const int hy = row % HS; row /= HS;
+      const int dz = row % DS;
+      const int cl = row / DS;
+      const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + q - 1;
+      float o = 0.f;
+      if (c0 + cl < a.Cin && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) {
+        const float x = xn[(long)cl * V + ((long)d * a.H + h) * a.W + w];
+        o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], x, xcoef[32 + cl]), 0.f) : x;
+      }
+      Xs[cl * XS + (dz * HS + hy) * RS + q] = o;
+    }
+    // ---- stage dOut for the tile's 64 voxels ----
+#pragma unroll 4
+    for (int it = tid; it < 32 * 64; it += NTHREADS) {
+      const int t = it & 63, m = it >> 6;
+      const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+      const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+      float o = 0.f;
+      if (m < a.M && d < a.D && h < a.H && w < a.W) {
+        const long g = (long)m * V + ((long)d * a.H + h) * a.W + w;
+        o = fmaf(gcoef[m], g0n[g], fmaf(gcoef[32 + m], g1n[g], gcoef[64 + m]));
+      }
+      Ys[m * YS + t] = o;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s0 = 0; s0 < 32; s0 += 8) {   // groups of 8 k-steps keep the operand prefetch inside the register budget
+      const int wx0 = s0 % TW, hy0 = (s0 / TW) % TH, dz0 = s0 / (TW * TH);
+      const float* xg = xl + (dz0 * HS + hy0) * RS + wx0;
+      const float* yg = yl + s0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p0 = (i / TW) * RS + (i % TW);   // a group never crosses a depth slice (TH*TW >= 16)
+        const float av = yg[i];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xg[p0 + kw], acc[kw], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partial result: slab[split][tap][m][c] ----
+  float* out = a.slab + (long)split * a.slab_stride;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, half);
+      if (m < a.M && c0 + l31 < a.Cin) out[((long)tap * a.M + m) * a.Cin + c0 + l31] = acc[kw][r];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// 1x1x1:  block = WC waves, each owning 32 input channels x all 128 rows of one m-group (4 accumulator tiles).
+// ----------------------------------------------------------------------------------------------------------------
+template <int WC>
+struct Wg1Cfg {
+  static constexpr int VK = 64, S = VK + 1;
+  static constexpr int NTHREADS = WC * 64;
+  static size_t smem_bytes() { return sizeof(float) * (128 * S + 32 * WC * S + 3 * 128 + 2 * 32 * WC + 3 * 128); }
+};
+
+template <int PRO_X, int WC>
+__global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
+  using C = Wg1Cfg<WC>;
+  constexpr int S = C::S, VK = C::VK, NTHREADS = C::NTHREADS, CB = 32 * WC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [128 m][S]
+  float* Bs = As + 128 * S;          // [CB c][S]
+  float* gcoef = Bs + CB * S;        // p,q,r x 128
+  float* xcoef = gcoef + 384;        // a,b x CB
+  float* gbase = xcoef + 2 * CB;     // p,q,r before the per-sample dropout scale
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int V = a.D * a.H * a.W;
+  const int split = blockIdx.x, c0 = blockIdx.y * CB, m0 = blockIdx.z * 128;
+  const int chunks_per_n = (V + VK - 1) / VK;
+  const int nchunks = a.N * chunks_per_n;
+  const int k_begin = (int)((long)nchunks * split / a.nsplit), k_end = (int)((long)nchunks * (split + 1) / a.nsplit);
+
+  for (int c = tid; c < CB; c += NTHREADS) {
+    float ca = 0.f, cb = 0.f, mu, rs;
+    if (PRO_X == PRO_BNRELU && c0 + c < a.Cin) bn_fwd_coef(a.bn, c0 + c, ca, cb, mu, rs);
+    xcoef[c] = ca; xcoef[CB + c] = cb;
+  }
+  for (int m = tid; m < 128; m += NTHREADS) {
+    float p = 0.f, q = 0.f, r = 0.f;
+    if (m0 + m < a.M) bn_bwd_coef(a.gr, m0 + m, p, q, r);
+    gbase[m] = p; gbase[128 + m] = q; gbase[256 + m] = r;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* al = As + l31 * S + 32 * half;
+  const float* bl = Bs + (wave * 32 + l31) * S + 32 * half;
+  const bool vec = (V & 3) == 0;
+
+  int cur_n = -1;
+  for (int ch = k_begin; ch < k_end; ++ch) {
+    const int n = ch / chunks_per_n;
+    const int v0 = (ch % chunks_per_n) * VK;
+    if (n != cur_n) {
+      __syncthreads();
+      for (int m = tid; m < 128; m += NTHREADS) {
+        const float s = drop_scale(a.drop, n, m0 + m);
+        gcoef[m] = gbase[m] * s; gcoef[128 + m] = gbase[128 + m] * s; gcoef[256 + m] = gbase[256 + m] * s;
+      }
+      cur_n = n;
+      __syncthreads();
+    }
+    const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
+    const float* g0n = a.g0 + (long)n * a.g0_ns + (long)(a.g0_coff + m0) * V;
+    const float* g1n = a.g1 + (long)n * a.g1_ns + (long)(a.g1_coff + m0) * V;
+    if (vec) {
+#pragma unroll 2
+      for (int it = tid; it < 128 * (VK / 4); it += NTHREADS) {
+        const int q = it % (VK / 4), m = it / (VK / 4);
+        const int v = v0 + 4 * q;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + m < a.M && v < V) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(g0n + (long)m * V + v);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(g1n + (long)m * V + v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(gcoef[m], g0[e], fmaf(gcoef[128 + m], g1[e], gcoef[256 + m]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[m * S + 4 * q + e] = o[e];
+      }
+#pragma unroll 2
+      for (int it = tid; it < CB * (VK / 4); it += NTHREADS) {
+        const int q = it % (VK / 4), c = it / (VK / 4);
+        const int v = v0 + 4 * q;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + c < a.Cin && v < V) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(xn + (long)c * V + v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[c], x[e], xcoef[CB + c]), 0.f) : x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[c * S + 4 * q + e] = o[e];
+      }
+    } else {
+#pragma unroll 2
+      for (int it = tid; it < 128 * VK; it += NTHREADS) {
+        const int q = it % VK, m = it / VK;
+        const int v = v0 + q;
+        float o = 0.f;
+        if (m0 + m < a.M && v < V) o = fmaf(gcoef[m], g0n[(long)m * V + v], fmaf(gcoef[128 + m], g1n[(long)m * V + v], gcoef[256 + m]));
+        As[m * S + q] = o;
+      }
+#pragma unroll 2
+      for (int it = tid; it < CB * VK; it += NTHREADS) {
+        const int q = it % VK, c = it / VK;
+        const int v = v0 + q;
+        float o = 0.f;
+        if (c0 + c < a.Cin && v < V) {
+          const float x = xn[(long)c * V + v];
+          o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[c], x, xcoef[CB + c]), 0.f) : x;
+        }
+        Bs[c * S + q] = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s0 = 0; s0 < 32; s0 += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float bv = bl[s0 + i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(al[t * 32 * S + s0 + i], bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.slab + (long)split * a.slab_stride;
+  const int c = c0 + wave * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + t * 32 + acc_row(r, half);
+      if (m < a.M && c < a.Cin) out[(long)m * a.Cin + c] = acc[t][r];
+    }
+}
+
+#endif  // __HIPCC__
+}  // namespace mmnn
