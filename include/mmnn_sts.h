@@ -58,8 +58,74 @@ int mmnn_densenet_forward(void* plan, const float* params, float* runstats, cons
  * training forward untouched.  grad_params: flat, same layout as params; accumulate != 0 adds into it. */
 int mmnn_densenet_backward(void* plan, const float* params, const float* x, void* workspace, const float* grad_out,
                            float* grad_params, int32_t accumulate, uint64_t seed, void* stream);
+/* introspection: the ReLU decisions (a*x+b > 0, uint8 [n][C][V]) of one BN+ReLU site of the last training forward.
+ * kind 0: relu0 (models/densenet.py:201); 1: denselayer relu1 (:77); 2: relu2 (:81); 3: transition relu (:146).
+ * Used by the gradient parity tests (ReLU is not differentiable at 0: a reference must take the same branch). */
+int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, int32_t kind, int32_t block, int32_t layer,
+                            uint8_t* out, void* stream);
 /* byte offset of a named workspace region (tests / GradCAM): "x","g","t1","conv0","st_x",... ; -1 if unknown */
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j);
+
+/* ---- DenseNet.features: ReLU -> AdaptiveAvgPool3d(1) -> flatten -> Linear -> Dropout (models/densenet.py:234-247) ---- */
+/* h [n][c][v] (norm5 output), w [f][c], b [f] -> out [n][f]; pooled [n][c] is saved for the backward. */
+int mmnn_gap_linear_forward(int32_t n, int32_t c, int32_t v, int32_t f, const float* h, const float* w, const float* b,
+                            float* pooled, float* out, float dropout_prob, uint64_t seed, int32_t training, void* stream);
+int mmnn_gap_linear_backward(int32_t n, int32_t c, int32_t v, int32_t f, const float* h, const float* w, const float* pooled,
+                             const float* dout, float* dw, float* db, float* dh, float dropout_prob, uint64_t seed,
+                             int32_t training, int32_t accumulate, void* stream);
+
+/* ---- [Linear -> BatchNorm1d -> ReLU / Dropout1d] stacks: MLP.backbone, MLP.features (models/mlp.py:19-51) ---------- */
+#define MMNN_MLP_MAX_LAYERS 8
+typedef struct {
+  int32_t n;                                  /* batch rows */
+  int32_t num_layers;
+  int32_t in_dim[MMNN_MLP_MAX_LAYERS];
+  int32_t out_dim[MMNN_MLP_MAX_LAYERS];
+  int32_t relu_first[MMNN_MLP_MAX_LAYERS];    /* 1: dense-bn-relu-drop (mlp.py:21-24); 0: dense-bn-drop-relu (:25-49) */
+  float dropout_prob;                         /* nn.Dropout1d on a 2-D input: whole ROWS are dropped */
+  float eps, momentum;
+  uint64_t seed;
+  int32_t training;
+  int32_t first_layer_id;                     /* dropout stream id of layer 0 of this stack */
+} mmnn_mlp_desc;
+typedef struct {
+  const float* weight[MMNN_MLP_MAX_LAYERS];   /* [out][in] */
+  const float* bias[MMNN_MLP_MAX_LAYERS];
+  const float* gamma[MMNN_MLP_MAX_LAYERS];
+  const float* beta[MMNN_MLP_MAX_LAYERS];
+  float* running_mean[MMNN_MLP_MAX_LAYERS];
+  float* running_var[MMNN_MLP_MAX_LAYERS];
+  float* grad_weight[MMNN_MLP_MAX_LAYERS];    /* backward only */
+  float* grad_bias[MMNN_MLP_MAX_LAYERS];
+  float* grad_gamma[MMNN_MLP_MAX_LAYERS];
+  float* grad_beta[MMNN_MLP_MAX_LAYERS];
+} mmnn_mlp_params;
+int64_t mmnn_mlp_saved_floats(const mmnn_mlp_desc* d);      /* size of `saved` */
+int mmnn_mlp_forward(const mmnn_mlp_desc* d, const mmnn_mlp_params* p, const float* x, float* out, float* saved, void* stream);
+/* scratch: 2 * n * max(dim) floats; dx may be NULL */
+int mmnn_mlp_backward(const mmnn_mlp_desc* d, const mmnn_mlp_params* p, const float* x, const float* saved, const float* dy,
+                      float* dx, float* scratch, int32_t accumulate, void* stream);
+
+/* ---- fusion heads (models/multimodal.py:62-77): out[0] = cat(fi,fc) Wf^T + bf; blend: out[1] = image head, out[2] = clinical */
+int mmnn_fusion_heads_forward(int32_t n, int32_t f, int32_t c, int32_t blend, const float* fi, const float* fc, const float* wf,
+                              const float* bf, const float* wi, const float* bi, const float* wc, const float* bc, float* out,
+                              void* stream);
+int mmnn_fusion_heads_backward(int32_t n, int32_t f, int32_t c, int32_t blend, const float* fi, const float* fc, const float* wf,
+                               const float* wi, const float* wc, const float* dout, float* dfi, float* dfc, float* dwf, float* dbf,
+                               float* dwi, float* dbi, float* dwc, float* dbc, int32_t accumulate, void* stream);
+
+/* ---- small dense layer y = x W^T + b: class_layers.out (models/densenet.py:250-256), MLP.output_head (mlp.py:53-57) - */
+int mmnn_linear_forward(int32_t n, int32_t d, int32_t o, const float* x, const float* w, const float* b, float* y, void* stream);
+int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const float* w, const float* dy, float* dx, float* dw,
+                         float* db, int32_t accumulate, void* stream);
+
+/* ---- Cox partial likelihood summed over targets and blended over heads (losses/losses.py:6-9 -> pycox CoxPHLoss,
+ * utils/utils.py:24-29, losses/GradientBlender.py:197-205).  preds [heads][n][c]; sort_key / weight [n][c] int64: pycox's
+ * `durations` / `events` arguments (the reference passes events / durations there, in that order).  Stable descending sort.
+ * Writes loss = sum_h head_weights[h] * head_losses[h] (head_weights NULL: all 1), head_losses[h] = sum_c cox(h, c), and
+ * grad_preds = d loss / d preds.  scratch: 4 * n floats. */
+int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const int64_t* sort_key, const int64_t* weight,
+                        const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

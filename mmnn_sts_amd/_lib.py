@@ -17,6 +17,23 @@ class DenseNetConfig(Structure):
     ]
 
 
+MLP_MAX_LAYERS = 8
+_FP = POINTER(c_float)
+
+
+class MlpDesc(Structure):
+    _fields_ = [
+        ("n", c_int32), ("num_layers", c_int32), ("in_dim", c_int32 * MLP_MAX_LAYERS), ("out_dim", c_int32 * MLP_MAX_LAYERS),
+        ("relu_first", c_int32 * MLP_MAX_LAYERS), ("dropout_prob", c_float), ("eps", c_float), ("momentum", c_float),
+        ("seed", c_uint64), ("training", c_int32), ("first_layer_id", c_int32),
+    ]
+
+
+class MlpParams(Structure):
+    _fields_ = [(k, c_void_p * MLP_MAX_LAYERS) for k in (
+        "weight", "bias", "gamma", "beta", "running_mean", "running_var", "grad_weight", "grad_bias", "grad_gamma", "grad_beta")]
+
+
 def lib():
     """Load the shared library once (torch must be imported first so that its HIP runtime is the one bound)."""
     global _lib
@@ -43,8 +60,28 @@ def lib():
     L.mmnn_densenet_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
     L.mmnn_densenet_backward.restype = c_int32
     L.mmnn_densenet_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
+    L.mmnn_densenet_relu_mask.restype = c_int32
+    L.mmnn_densenet_relu_mask.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     L.mmnn_densenet_ws_offset.restype = c_int64
     L.mmnn_densenet_ws_offset.argtypes = [c_void_p, c_char_p, c_int32, c_int32]
+    V, I, U, F = c_void_p, c_int32, c_uint64, c_float
+    sigs = {
+        "mmnn_gap_linear_forward": [I, I, I, I, V, V, V, V, V, F, U, I, V],
+        "mmnn_gap_linear_backward": [I, I, I, I, V, V, V, V, V, V, V, F, U, I, I, V],
+        "mmnn_mlp_forward": [POINTER(MlpDesc), POINTER(MlpParams), V, V, V, V],
+        "mmnn_mlp_backward": [POINTER(MlpDesc), POINTER(MlpParams), V, V, V, V, V, I, V],
+        "mmnn_fusion_heads_forward": [I, I, I, I] + [V] * 9 + [V],
+        "mmnn_fusion_heads_backward": [I, I, I, I] + [V] * 14 + [I, V],
+        "mmnn_linear_forward": [I, I, I, V, V, V, V, V],
+        "mmnn_linear_backward": [I, I, I, V, V, V, V, V, V, I, V],
+        "mmnn_cox_blend_loss": [I, I, I, V, V, V, V, V, V, V, V, V],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = c_int32
+        fn.argtypes = args
+    L.mmnn_mlp_saved_floats.restype = c_int64
+    L.mmnn_mlp_saved_floats.argtypes = [POINTER(MlpDesc)]
     _lib = L
     return L
 

@@ -59,6 +59,13 @@ int mmnn_densenet_backward(void* plan, const float* params, const float* x, void
                        static_cast<hipStream_t>(stream));
 }
 
+int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, int32_t kind, int32_t block, int32_t layer,
+                            uint8_t* out, void* stream) {
+  MMNN_REQUIRE(plan && out, "relu_mask: null argument");
+  return plan_relu_mask(*static_cast<Plan*>(plan), params, static_cast<char*>(workspace), kind, block, layer, out,
+                        static_cast<hipStream_t>(stream));
+}
+
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j) {
   if (!plan || !name) return -1;
   return plan_ws_offset(*static_cast<const Plan*>(plan), name, i, j);

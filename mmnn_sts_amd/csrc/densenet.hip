@@ -547,6 +547,40 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), p.n_grad_jobs, p.max_grad, grad_params, accumulate, stream);
 }
 
+int plan_relu_mask(Plan& p, const float* params, char* ws, int kind, int b, int l, unsigned char* out, hipStream_t stream) {
+  MMNN_REQUIRE(p.tab_ws == ws && p.tab_params == params, "relu_mask: must follow a training forward on the same buffers");
+  const NetCfg& c = p.cfg;
+  float* run = p.tab_run;
+  MaskArgs a;
+  a.out = out; a.N = p.N;
+  if (kind == 0) {
+    a.C = c.init_features; a.V = p.D0 * p.H0 * p.W0;
+    a.x = fptr(ws, p.o_conv0); a.x_ns = (long)a.C * a.V;
+    a.bn = bnfwd(p, statptr(ws, p.o_st_conv0, c.init_features, 0), params, run, p.p_n0w, p.p_n0b, p.r_n0m, p.r_n0v, (double)p.N * a.V, 1);
+    return launch_relu_mask(a, stream);
+  }
+  MMNN_REQUIRE(b >= 0 && b < c.nblocks, "relu_mask: bad block %d", b);
+  const double cnt = (double)p.N * p.Vb[b];
+  a.V = p.Vb[b];
+  if (kind == 3) {
+    MMNN_REQUIRE(b < c.nblocks - 1, "relu_mask: block %d has no transition", b);
+    const TransOff& t = p.trans[b];
+    a.C = t.cin; a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, t.nw, t.nb, t.rm, t.rv, cnt, 1);
+    return launch_relu_mask(a, stream);
+  }
+  MMNN_REQUIRE(l >= 0 && l < c.block_layers[b] && (kind == 1 || kind == 2), "relu_mask: bad site (%d,%d,%d)", kind, b, l);
+  const LayerOff& lo = p.layers[b][l];
+  if (kind == 1) {
+    a.C = lo.cin; a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+  } else {
+    a.C = p.mid; a.x = fptr(ws, p.o_t1[b][l]); a.x_ns = (long)p.mid * p.Vb[b];
+    a.bn = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+  }
+  return launch_relu_mask(a, stream);
+}
+
 long plan_ws_offset(const Plan& p, const char* name, int i, int j) {
   const std::string s(name);
   const int nb = p.cfg.nblocks;

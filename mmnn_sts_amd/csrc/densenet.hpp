@@ -73,5 +73,8 @@ int plan_forward(Plan& p, const float* params, float* runstats, const float* x, 
 int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params,
                   int accumulate, uint64_t seed, hipStream_t stream);
 long plan_ws_offset(const Plan& p, const char* name, int i, int j);
+// ReLU decisions of one BN+ReLU site after a training forward: kind 0 = relu0 (stem), 1 = layer relu1, 2 = layer relu2,
+// 3 = transition relu.  out: uint8 [N][C][V] of that site.
+int plan_relu_mask(Plan& p, const float* params, char* ws, int kind, int b, int l, unsigned char* out, hipStream_t stream);
 
 }  // namespace mmnn

@@ -64,6 +64,25 @@ int launch_bn_apply(const BnApplyArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) relu_mask_kernel(const MaskArgs a) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float* xc = a.x + (long)n * a.x_ns + (long)c * a.V;
+  unsigned char* oc = a.out + ((long)n * a.C + c) * a.V;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < a.V; v += gridDim.x * 256) oc[v] = fmaf(ca, xc[v], cb) > 0.f ? 1 : 0;
+}
+
+int launch_relu_mask(const MaskArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.V > 0 && a.N <= 65535 && a.C <= 65535 && a.out, "relu_mask: bad arguments");
+  int gx = cdiv(a.V, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) consumer_bwd_kernel(const ConsumerBwdArgs a) {
   __shared__ float red[2][4];
   const int c = blockIdx.y, n = blockIdx.z;

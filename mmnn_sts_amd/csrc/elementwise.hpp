@@ -38,6 +38,15 @@ struct ConsumerBwdArgs {
 };
 int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream);
 
+// ---- introspection (tests, GradCAM): mask[n][c][v] = (a_c*x + b_c > 0), the exact ReLU decision the kernels take
+struct MaskArgs {
+  int N, C, V;
+  const float* x; long x_ns;
+  BnFwd bn;
+  unsigned char* out;         // [N][C][V]
+};
+int launch_relu_mask(const MaskArgs& a, hipStream_t stream);
+
 // ---- running statistics: rm = (1-mom)*rm + mom*mean ; rv = (1-mom)*rv + mom*var*n/(n-1)   for a table of BN layers
 struct RunStatJob {
   const double* sum; const double* sq; int stride; int off; int C;

@@ -54,7 +54,7 @@ struct FpropCfg {
   static constexpr int DS = (TAPS == 27) ? TD + 2 : 1;
   static constexpr int XS = DS * HS * RS;
   static constexpr int NCOEF = (PRO == PRO_BNRELU) ? 2 : (PRO == PRO_GRAD ? 3 : 0);
-  static constexpr int ECOEF = 8;   // per output row: a, b, mean, rstd, gamma, dropscale, red0, red1
+  static constexpr int ECOEF = 6 + 2 * WN;   // per output row: a, b, mean, rstd, gamma, dropscale, then per-wave partial sums
   static_assert(TD * TH * TW == V_B, "tile volume must equal the block's voxel count");
   static_assert(KC % 2 == 0, "channel chunk must be even (two channels per MFMA)");
   static size_t smem_bytes(int Cin) {
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
       if (EPI == EPI_STORE_STATS) ds = drop_scale(a.drop_out, n, m0 + m);
     }
     ecoef[m] = ea; ecoef[M_B + m] = eb; ecoef[2 * M_B + m] = mu; ecoef[3 * M_B + m] = rs;
-    ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds; ecoef[6 * M_B + m] = 0.f; ecoef[7 * M_B + m] = 0.f;
+    ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds;
   }
   __syncthreads();
 
@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
 
   const float* in0n = a.in0 + (long)n * a.in0_ns + (long)a.in0_coff * V;
   const float* in1n = (PRO == PRO_GRAD) ? a.in1 + (long)n * a.in1_ns + (long)a.in1_coff * V : nullptr;
-  const bool vecx = (TAPS == 27) ? ((a.W & 3) == 0) : ((V & 3) == 0);
-  const bool vecw = ((a.w_ld & 3) == 0) && ((a.M & 3) == 0);
+  const bool al_x = (((uintptr_t)in0n | (uintptr_t)in1n) & 15) == 0;
+  const bool vecx = al_x && ((TAPS == 27) ? ((a.W & 3) == 0) : ((V & 3) == 0));
+  const bool vecw = ((a.w_ld & 3) == 0) && ((a.M & 3) == 0) && (((uintptr_t)a.w & 15) == 0);
 
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
     // ================= stage activations =================
@@ -314,8 +315,8 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
   }
 
   // ================= epilogue =================
-  float* red0 = ecoef + 6 * M_B;
-  float* red1 = ecoef + 7 * M_B;
+  float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
+  float* red1 = red0 + WN * M_B;
   float* outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
   const float* exn = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) ? a.ex + (long)n * a.ex_ns + (long)a.ex_coff * V : nullptr;
   const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
@@ -379,8 +380,8 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
       const float r1 = half_reduce16(s1, lane);
       if ((lane & 1) == 0) {
         const int ml = wm * MT * 32 + i * 32 + acc_row((l31 >> 1) & 15, half);
-        atomicAdd(&red0[ml], r0);
-        atomicAdd(&red1[ml], r1);
+        red0[wn * M_B + ml] = r0;
+        red1[wn * M_B + ml] = r1;
       }
     }
   }
@@ -388,7 +389,9 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
     __syncthreads();
     for (int m = tid; m < M_B; m += NTHREADS) {
       if (m0 + m >= a.M) continue;
-      const double v0d = (double)red0[m], v1d = (double)red1[m];
+      double v0d = 0.0, v1d = 0.0;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) { v0d += (double)red0[j * M_B + m]; v1d += (double)red1[j * M_B + m]; }
       if (EPI == EPI_STORE_STATS) {
         atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + m0 + m, v0d);
         atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + m0 + m, v1d);

@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
   const int krows = PAIR_C ? a.Cin * 49 : a.Cin * 56;
   float* Xs = smem;                           // [Cin][2][13][72]
   float* Ws = Xs + a.Cin * SC_CS;             // [krows][64]
-  float* red = Ws + krows * 64;               // [2][64]
+  float* red = Ws + krows * 64;               // [4 waves][2][64] per-wave partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int Vi = a.D * a.H * a.W, Vo = a.Do * a.Ho * a.Wo;
   int b = blockIdx.x;
@@ -33,7 +33,6 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
   const int do0 = (b % nd) * SC_TD; b /= nd;
   const int n = b;
   const int rep = blockIdx.x & (NREP - 1);
-  if (tid < 128) red[tid] = 0.f;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -144,16 +143,18 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
       const float r0 = half_reduce16(s0, lane), r1 = half_reduce16(s1, lane);
       if ((lane & 1) == 0) {
         const int m = i * 32 + acc_row((l31 >> 1) & 15, half);
-        atomicAdd(&red[m], r0);
-        atomicAdd(&red[64 + m], r1);
+        red[wave * 128 + m] = r0;
+        red[wave * 128 + 64 + m] = r1;
       }
     }
   }
   if (want) {
     __syncthreads();
     if (tid < a.M) {
-      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + tid, (double)red[tid]);
-      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + tid, (double)red[64 + tid]);
+      double v0 = 0.0, v1 = 0.0;
+      for (int j = 0; j < 4; ++j) { v0 += (double)red[j * 128 + tid]; v1 += (double)red[j * 128 + 64 + tid]; }
+      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + tid, v0);
+      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + tid, v1);
     }
   }
 }
@@ -164,7 +165,7 @@ int launch_stem_conv(const StemConvArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.Do == (a.D - 1) / 2 + 1 && a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1, "stem conv: output extent mismatch");
   MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "stem conv: volume too large");
   const int krows = stem_krows(a.Cin);
-  const size_t smem = sizeof(float) * ((size_t)a.Cin * SC_CS + (size_t)krows * 64 + 128);
+  const size_t smem = sizeof(float) * ((size_t)a.Cin * SC_CS + (size_t)krows * 64 + 512);
   const long blocks = (long)a.N * cdiv(a.Do, SC_TD) * cdiv(a.Ho, SC_TH) * cdiv(a.Wo, SC_TW);
   MMNN_REQUIRE(blocks < (1l << 31) && smem <= 160 * 1024, "stem conv: launch out of range");
   const bool pair_c = (a.Cin % 2 == 0);

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const float* al = As + l31 * S + 32 * half;
   const float* bl = Bs + (wave * 32 + l31) * S + 32 * half;
-  const bool vec = (V & 3) == 0;
+  const bool vec = (V & 3) == 0 && ((((uintptr_t)a.x | (uintptr_t)a.g0 | (uintptr_t)a.g1) & 15) == 0);
 
   int cur_n = -1;
   for (int ch = k_begin; ch < k_end; ++ch) {

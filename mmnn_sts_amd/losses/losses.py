@@ -1,0 +1,24 @@
+"""Cox partial-likelihood loss of the reference (losses/losses.py:6-9), on the MI355X.
+
+The reference calls `pycox.models.loss.CoxPHLoss()(log_h, events, duration)`, i.e. it forwards its arguments POSITIONALLY
+into pycox's `(log_h, durations, events)`: the event flags end up as the sort key and the durations as the weights
+(SURVEY 8(a) A9).  That call is reproduced verbatim; `intended_order=True` gives pycox's documented semantics.
+The sort is a STABLE descending sort (torch.sort's tie order is unspecified for n > 16).
+"""
+import torch
+
+from .. import ops
+
+NUM_CLASSES = 2
+
+
+def cox_ph_loss(log_h: torch.Tensor, durations: torch.Tensor, events: torch.Tensor) -> torch.Tensor:
+    """pycox `CoxPHLoss.forward(log_h, durations, events)` for one target vector."""
+    loss, _ = ops.CoxBlend.apply(log_h.reshape(1, -1, 1), durations.reshape(-1, 1), events.reshape(-1, 1), None)
+    return loss
+
+
+def CoxPH(log_h, events, duration, intended_order: bool = False):
+    if intended_order:
+        return cox_ph_loss(log_h, duration, events)
+    return cox_ph_loss(log_h, events, duration)

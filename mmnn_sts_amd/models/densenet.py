@@ -1,0 +1,311 @@
+"""MI355X-native mirror of the reference's 3-D DenseNet (models/densenet.py:151-356 of DigITs-AIML/MMNN_STS).
+
+Same constructor signature, same attribute names (`backbone`, `features`, `class_layers`) and the same `state_dict`
+schema as the reference, so checkpoints and callers (`utils.BackpropagatableFeatureExtractor`, `MultiModalModel`,
+`parser.getModel`) are interchangeable -- but `backbone.forward` / `features.forward` run hand-written HIP kernels
+through the C-ABI (include/mmnn_sts.h).  The torch.nn sub-modules below are PARAMETER CONTAINERS ONLY: their own
+`forward` is never called; all their parameters are views into one flat fp32 buffer the kernels index directly.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+
+__all__ = ["DenseNet", "DenseNet121", "TinyDensenet"]
+
+
+class _DenseLayer(nn.Module):
+    """Container for norm1/relu1/conv1/norm2/relu2/conv2[/dropout] (reference `_DenseLayer`, models/densenet.py:46-89)."""
+
+    def __init__(self, in_channels: int, growth_rate: int, bn_size: int, dropout_prob: float):
+        super().__init__()
+        mid = bn_size * growth_rate
+        self.layers = nn.Sequential()
+        self.layers.add_module("norm1", nn.BatchNorm3d(in_channels))
+        self.layers.add_module("relu1", nn.ReLU(inplace=True))
+        self.layers.add_module("conv1", nn.Conv3d(in_channels, mid, kernel_size=1, bias=False))
+        self.layers.add_module("norm2", nn.BatchNorm3d(mid))
+        self.layers.add_module("relu2", nn.ReLU(inplace=True))
+        self.layers.add_module("conv2", nn.Conv3d(mid, growth_rate, kernel_size=3, padding=1, bias=False))
+        if dropout_prob > 0:
+            self.layers.add_module("dropout", nn.Dropout3d(dropout_prob))
+
+
+class _Backbone(nn.Sequential):
+    """conv0 .. norm5 (models/densenet.py:196-231).  forward(x) = one C-ABI call into the HIP launch plan."""
+
+    _MAX_PLANS = 3
+
+    def __init__(self, in_channels, init_features, growth_rate, block_config, bn_size, dropout_prob):
+        super().__init__()
+        self.cfg = dict(in_channels=in_channels, init_features=init_features, growth_rate=growth_rate,
+                        block_config=tuple(block_config), bn_size=bn_size, dropout_prob=float(dropout_prob))
+        self.add_module("conv0", nn.Conv3d(in_channels, init_features, kernel_size=7, stride=2, padding=3, bias=False))
+        self.add_module("norm0", nn.BatchNorm3d(init_features))
+        self.add_module("relu0", nn.ReLU(inplace=True))
+        self.add_module("pool0", nn.MaxPool3d(kernel_size=3, stride=2, padding=1))
+        c = init_features
+        for i, n_layers in enumerate(block_config):
+            block = nn.Sequential()
+            for j in range(n_layers):
+                block.add_module(f"denselayer{j + 1}", _DenseLayer(c, growth_rate, bn_size, dropout_prob))
+                c += growth_rate
+            self.add_module(f"denseblock{i + 1}", block)
+            if i == len(block_config) - 1:
+                self.add_module("norm5", nn.BatchNorm3d(c))
+            else:
+                trans = nn.Sequential()
+                trans.add_module("norm", nn.BatchNorm3d(c))
+                trans.add_module("relu", nn.ReLU(inplace=True))
+                trans.add_module("conv", nn.Conv3d(c, c // 2, kernel_size=1, bias=False))
+                trans.add_module("pool", nn.AvgPool3d(kernel_size=2, stride=2))
+                self.add_module(f"transition{i + 1}", trans)
+                c //= 2
+        self.out_channels = c
+        # non-module state (kept out of state_dict)
+        object.__setattr__(self, "_flat", None)
+        object.__setattr__(self, "_flat_run", None)
+        object.__setattr__(self, "_flat_grad", None)
+        object.__setattr__(self, "_plans", OrderedDict())
+        object.__setattr__(self, "_anchor", None)
+        object.__setattr__(self, "_fwd_token", 0)
+
+    # ---- flat parameter storage -------------------------------------------------------------------------------------
+    def _bn_modules(self):
+        return [m for m in self.modules() if isinstance(m, nn.BatchNorm3d)]
+
+    def _flatten(self) -> None:
+        params = list(self.parameters())
+        dev = params[0].device
+        flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        bns = self._bn_modules()
+        run = torch.cat([t.detach().reshape(-1).to(torch.float32) for m in bns for t in (m.running_mean, m.running_var)])
+        off = 0
+        for m in bns:
+            c = m.num_features
+            m.running_mean.data = run[off:off + c]
+            m.running_var.data = run[off + c:off + 2 * c]
+            off += 2 * c
+        nbt = torch.stack([m.num_batches_tracked.detach() for m in bns]).to(torch.int64)
+        for i, m in enumerate(bns):
+            m.num_batches_tracked.data = nbt[i]
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_flat_run", run)
+        object.__setattr__(self, "_flat_nbt", nbt)
+        object.__setattr__(self, "_flat_grad", None)
+        object.__setattr__(self, "_params", params)
+        object.__setattr__(self, "_anchor", torch.zeros(1, device=dev, requires_grad=True))
+        for p in params:
+            p.grad = None
+
+    def _storage_ok(self) -> bool:
+        flat = self._flat
+        if flat is None:
+            return False
+        base, off = flat.data_ptr(), 0
+        for p in self._params:
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+            off += p.numel()
+        m = self._bn_modules()[-1]
+        return m.running_var.data_ptr() == self._flat_run.data_ptr() + 4 * (self._flat_run.numel() - m.num_features)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        object.__setattr__(self, "_flat", None)     # .to()/.cuda()/.float() re-allocate every tensor: re-flatten lazily
+        return out
+
+    # ---- plans --------------------------------------------------------------------------------------------------------
+    def _plan_for(self, x: torch.Tensor):
+        key = (tuple(x.shape), x.device.index)
+        ent = self._plans.get(key)
+        if ent is not None:
+            self._plans.move_to_end(key)
+            return ent
+        L = _lib.lib()
+        c = self.cfg
+        bc = list(c["block_config"]) + [0] * (8 - len(c["block_config"]))
+        ccfg = _lib.DenseNetConfig(c["in_channels"], c["init_features"], c["growth_rate"], c["bn_size"], len(c["block_config"]),
+                                   (ctypes.c_int32 * 8)(*bc), self.norm0.eps, self.norm0.momentum or 0.1, c["dropout_prob"])
+        n, _, d, h, w = x.shape
+        plan = L.mmnn_densenet_plan_create(ctypes.byref(ccfg), n, d, h, w)
+        if not plan:
+            raise ValueError("mmnn_densenet_plan_create: " + _lib.last_error())
+        if L.mmnn_densenet_param_count(plan) != self._flat.numel() or L.mmnn_densenet_runstat_count(plan) != self._flat_run.numel():
+            L.mmnn_densenet_plan_destroy(plan)
+            raise RuntimeError("parameter layout mismatch between the Python module tree and the native plan")
+        shp = [ctypes.c_int32() for _ in range(4)]
+        _lib.check(L.mmnn_densenet_out_shape(plan, *[ctypes.byref(v) for v in shp]), "out_shape")
+        ws = torch.empty(L.mmnn_densenet_workspace_bytes(plan), dtype=torch.uint8, device=x.device)
+        ent = {"plan": plan, "ws": ws, "out_shape": (n,) + tuple(v.value for v in shp)}
+        self._plans[key] = ent
+        while len(self._plans) > self._MAX_PLANS:
+            _, old = self._plans.popitem(last=False)
+            L.mmnn_densenet_plan_destroy(old["plan"])
+        return ent
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for ent in self._plans.values():
+                L.mmnn_densenet_plan_destroy(ent["plan"])
+        except Exception:
+            pass
+
+    # ---- execution ----------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("mmnn_sts_amd: the DenseNet backbone runs on the MI355X only (no CPU path); move model and input to cuda")
+        if x.dim() != 5 or x.shape[1] != self.cfg["in_channels"]:
+            raise ValueError(f"expected (N, {self.cfg['in_channels']}, D, H, W) input, got {tuple(x.shape)}")
+        x = x.detach()
+        x = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        if not self._storage_ok():
+            self._flatten()
+        if self._flat.device != x.device:
+            raise RuntimeError(f"model on {self._flat.device}, input on {x.device}")
+        if self.training and torch.is_grad_enabled():
+            return _BackboneFn.apply(x, self._anchor, self)
+        return self._run_forward(x, self.training)[0]
+
+    def _run_forward(self, x, training):
+        ent = self._plan_for(x)
+        out = torch.empty(ent["out_shape"], dtype=torch.float32, device=x.device)
+        seed = ops.next_seed()
+        _lib.check(_lib.lib().mmnn_densenet_forward(ent["plan"], self._flat.data_ptr(), self._flat_run.data_ptr(), x.data_ptr(),
+                                                    ent["ws"].data_ptr(), out.data_ptr(), int(training), seed,
+                                                    torch.cuda.current_stream().cuda_stream), "mmnn_densenet_forward")
+        if training:
+            self._flat_nbt.add_(1)
+        object.__setattr__(self, "_fwd_token", self._fwd_token + 1)
+        return out, ent, seed, self._fwd_token
+
+    def _run_backward(self, x, ent, seed, token, grad_out):
+        if token != self._fwd_token:
+            raise RuntimeError("mmnn_sts_amd: backward through a DenseNet backbone forward whose workspace has been overwritten by a "
+                               "later forward of the same module (one live forward per module is supported)")
+        params = self._params
+        gflat = self._flat_grad
+        fresh = gflat is None or params[0].grad is None or params[0].grad.data_ptr() != gflat.data_ptr()
+        if gflat is None:
+            gflat = torch.empty_like(self._flat)
+            object.__setattr__(self, "_flat_grad", gflat)
+        _lib.check(_lib.lib().mmnn_densenet_backward(ent["plan"], self._flat.data_ptr(), x.data_ptr(), ent["ws"].data_ptr(),
+                                                     grad_out.data_ptr(), gflat.data_ptr(), 0 if fresh else 1, seed,
+                                                     torch.cuda.current_stream().cuda_stream), "mmnn_densenet_backward")
+        if fresh:   # (re)attach .grad views; afterwards gradients accumulate inside the kernel until zero_grad() drops them
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad = gflat[off:off + n].view(p.shape)
+                off += n
+
+    # flat views for the fused optimizer / gradient all-reduce
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        if not self._storage_ok():
+            self._flatten()
+        return self._flat
+
+    @property
+    def flat_grad(self):
+        return self._flat_grad
+
+
+class _BackboneFn(torch.autograd.Function):
+    """Autograd node of the whole backbone.  Parameter gradients are written by the HIP backward straight into the
+    module's flat gradient buffer (the `.grad` of every parameter is a view of it), so nothing is returned for them."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module):
+        out, ent, seed, token = module._run_forward(x, True)
+        ctx.module, ctx.ent, ctx.seed, ctx.token = module, ent, seed, token
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        g = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.float().contiguous()
+        ctx.module._run_backward(x, ctx.ent, ctx.seed, ctx.token, g)
+        return None, None, None
+
+
+class _Features(nn.Sequential):
+    """relu -> AdaptiveAvgPool3d(1) -> flatten -> feature_layer -> dropout (models/densenet.py:234-247), one fused op."""
+
+    def __init__(self, in_channels: int, feature_channels: int, dropout_prob: float):
+        super().__init__(OrderedDict([
+            ("relu", nn.ReLU(inplace=True)), ("pool", nn.AdaptiveAvgPool3d(1)), ("flatten", nn.Flatten(1)),
+            ("feature_layer", nn.Linear(in_channels, feature_channels)), ("dropout", nn.Dropout(dropout_prob)),
+        ]))
+
+    def forward(self, h: torch.Tensor) -> torch.Tensor:
+        return ops.GapLinear.apply(h, self.feature_layer.weight, self.feature_layer.bias, float(self.dropout.p), self.training)
+
+
+class _ClassLayers(nn.Sequential):
+    def __init__(self, feature_channels: int, out_channels: int):
+        super().__init__(OrderedDict([("out", nn.Linear(feature_channels, out_channels))]))
+
+    def forward(self, f: torch.Tensor) -> torch.Tensor:
+        return ops.SmallLinear.apply(f, self.out.weight, self.out.bias)
+
+
+class DenseNet(nn.Module):
+    """Drop-in for `models.densenet.DenseNet` (models/densenet.py:151-271); 3-D, batch norm, ReLU only."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, feature_channels: int, init_features: int = 64,
+                 growth_rate: int = 32, block_config: Sequence[int] = (6, 12, 24, 16), bn_size: int = 4,
+                 act: Union[str, tuple] = ("relu", {"inplace": True}), norm: Union[str, tuple] = "batch",
+                 dropout_prob: float = 0.0) -> None:
+        super().__init__()
+        if spatial_dims != 3:
+            raise NotImplementedError("mmnn_sts_amd implements the 3-D DenseNet of the fusion path only (spatial_dims=3)")
+        if (act if isinstance(act, str) else act[0]).lower() != "relu" or (norm if isinstance(norm, str) else norm[0]).lower() != "batch":
+            raise NotImplementedError("mmnn_sts_amd kernels fuse ReLU + batch norm; other act/norm choices are not available")
+        self.backbone = _Backbone(in_channels, init_features, growth_rate, block_config, bn_size, dropout_prob)
+        self.features = _Features(self.backbone.out_channels, feature_channels, dropout_prob)
+        self.class_layers = _ClassLayers(feature_channels, out_channels)
+        for m in self.modules():      # models/densenet.py:258-265
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.class_layers(self.features(self.backbone(x)))
+
+
+class DenseNet121(DenseNet):
+    """models/densenet.py:312-331 (no pretrained 3-D weights exist upstream either)."""
+
+    def __init__(self, init_features: int = 64, growth_rate: int = 32, block_config: Sequence[int] = (6, 12, 24, 16),
+                 pretrained: bool = False, progress: bool = True, **kwargs) -> None:
+        super().__init__(init_features=init_features, growth_rate=growth_rate, block_config=block_config, **kwargs)
+        if pretrained:
+            raise NotImplementedError("Parameter `spatial_dims` is > 2 ; PyTorch Hub provides no pretrained 3-D DenseNet")
+
+
+class TinyDensenet(DenseNet):
+    """models/densenet.py:333-356: block_config (6, 12, 4)."""
+
+    def __init__(self, init_features: int = 64, growth_rate: int = 32, block_config: Sequence[int] = (6, 12, 4),
+                 pretrained: bool = False, progress: bool = True, **kwargs) -> None:
+        super().__init__(init_features=init_features, growth_rate=growth_rate, block_config=block_config, **kwargs)
+        if pretrained:
+            raise NotImplementedError("Parameter `spatial_dims` is > 2 ; PyTorch Hub provides no pretrained 3-D DenseNet")

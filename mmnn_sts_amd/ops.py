@@ -1,0 +1,239 @@
+"""torch.autograd.Function wrappers over the C-ABI (include/mmnn_sts.h).  PyTorch tensors are storage only: every
+forward/backward below is one or two launches of hand-written HIP kernels; there is no eager / CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mmnn_sts_amd: tensors must live on the MI355X (cuda) device; there is no CPU path")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_seed_counter = [0]
+
+
+def next_seed() -> int:
+    """Per-call dropout stream id, derived from torch's seed so `torch.manual_seed` makes runs repeatable."""
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DenseNet.features  (models/densenet.py:234-247)
+# ----------------------------------------------------------------------------------------------------------------------
+class GapLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, bias, p: float, training: bool):
+        _need_cuda(h, weight, bias)
+        h, weight, bias = _f32c(h), _f32c(weight), _f32c(bias)
+        n, c = h.shape[0], h.shape[1]
+        v = h[0, 0].numel()
+        f = weight.shape[0]
+        pooled = torch.empty((n, c), device=h.device, dtype=torch.float32)
+        out = torch.empty((n, f), device=h.device, dtype=torch.float32)
+        seed = next_seed()
+        _lib.check(_lib.lib().mmnn_gap_linear_forward(n, c, v, f, h.data_ptr(), weight.data_ptr(), bias.data_ptr(), pooled.data_ptr(),
+                                                      out.data_ptr(), float(p), seed, int(training), _stream()), "gap_linear_forward")
+        ctx.save_for_backward(h, weight, pooled)
+        ctx.meta = (n, c, v, f, float(p), seed, int(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, weight, pooled = ctx.saved_tensors
+        n, c, v, f, p, seed, training = ctx.meta
+        dout = _f32c(dout)
+        dw = torch.empty_like(weight)
+        db = torch.empty((f,), device=h.device, dtype=torch.float32)
+        dh = torch.empty_like(h)
+        _lib.check(_lib.lib().mmnn_gap_linear_backward(n, c, v, f, h.data_ptr(), weight.data_ptr(), pooled.data_ptr(), dout.data_ptr(),
+                                                       dw.data_ptr(), db.data_ptr(), dh.data_ptr(), p, seed, training, 0, _stream()),
+                   "gap_linear_backward")
+        return dh, dw, db, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# [Linear -> BatchNorm1d -> ReLU/Dropout1d] stacks  (models/mlp.py:19-51)
+# ----------------------------------------------------------------------------------------------------------------------
+def _mlp_desc(n, dims_in, dims_out, relu_first, p, eps, momentum, seed, training, first_id):
+    d = _lib.MlpDesc()
+    d.n, d.num_layers = n, len(dims_in)
+    for i, (a, b, r) in enumerate(zip(dims_in, dims_out, relu_first)):
+        d.in_dim[i], d.out_dim[i], d.relu_first[i] = a, b, int(r)
+    d.dropout_prob, d.eps, d.momentum, d.seed, d.training, d.first_layer_id = float(p), float(eps), float(momentum), seed, int(training), first_id
+    return d
+
+
+class MlpStack(torch.autograd.Function):
+    """inputs: x, then per layer (weight, bias, gamma, beta); running statistics are updated in place by the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, running, *params):
+        relu_first, p, eps, momentum, training, first_id = cfg
+        _need_cuda(x, *params)
+        x = _f32c(x)
+        nl = len(params) // 4
+        ws = [_f32c(t) for t in params]
+        dims_in = [ws[4 * i].shape[1] for i in range(nl)]
+        dims_out = [ws[4 * i].shape[0] for i in range(nl)]
+        n = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != dims_in[0]:
+            raise ValueError(f"MLP stack expects (N, {dims_in[0]}) input, got {tuple(x.shape)}")
+        seed = next_seed()
+        desc = _mlp_desc(n, dims_in, dims_out, relu_first, p, eps, momentum, seed, training, first_id)
+        pp = _lib.MlpParams()
+        for i in range(nl):
+            pp.weight[i], pp.bias[i], pp.gamma[i], pp.beta[i] = (ws[4 * i + j].data_ptr() for j in range(4))
+            pp.running_mean[i], pp.running_var[i] = running[2 * i].data_ptr(), running[2 * i + 1].data_ptr()
+        L = _lib.lib()
+        saved = torch.empty((max(1, L.mmnn_mlp_saved_floats(ctypes.byref(desc))),), device=x.device, dtype=torch.float32)
+        out = torch.empty((n, dims_out[-1]), device=x.device, dtype=torch.float32)
+        _lib.check(L.mmnn_mlp_forward(ctypes.byref(desc), ctypes.byref(pp), x.data_ptr(), out.data_ptr(), saved.data_ptr(), _stream()),
+                   "mlp_forward")
+        ctx.save_for_backward(x, saved, *ws)
+        ctx.desc_args = (n, dims_in, dims_out, relu_first, p, eps, momentum, seed, training, first_id)
+        ctx.running = running
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved, *ws = ctx.saved_tensors
+        n, dims_in, dims_out = ctx.desc_args[:3]
+        nl = len(dims_in)
+        desc = _mlp_desc(*ctx.desc_args)
+        pp = _lib.MlpParams()
+        grads = [torch.empty_like(w) for w in ws]
+        for i in range(nl):
+            pp.weight[i], pp.bias[i], pp.gamma[i], pp.beta[i] = (ws[4 * i + j].data_ptr() for j in range(4))
+            pp.running_mean[i], pp.running_var[i] = ctx.running[2 * i].data_ptr(), ctx.running[2 * i + 1].data_ptr()
+            pp.grad_weight[i], pp.grad_bias[i], pp.grad_gamma[i], pp.grad_beta[i] = (grads[4 * i + j].data_ptr() for j in range(4))
+        dy = _f32c(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty((2 * n * max(dims_in + dims_out),), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_mlp_backward(ctypes.byref(desc), ctypes.byref(pp), x.data_ptr(), saved.data_ptr(), dy.data_ptr(),
+                                                dx.data_ptr() if dx is not None else None, scratch.data_ptr(), 0, _stream()), "mlp_backward")
+        return (dx, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# small dense layer
+# ----------------------------------------------------------------------------------------------------------------------
+class SmallLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_cuda(x, weight, bias)
+        x, weight = _f32c(x), _f32c(weight)
+        bias = _f32c(bias) if bias is not None else None
+        n, d, o = x.shape[0], x.shape[1], weight.shape[0]
+        y = torch.empty((n, o), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_linear_forward(n, d, o, x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                  y.data_ptr(), _stream()), "linear_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, d, o = x.shape[0], x.shape[1], weight.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty((o,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        _lib.check(_lib.lib().mmnn_linear_backward(n, d, o, x.data_ptr(), weight.data_ptr(), dy.data_ptr(),
+                                                   dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+                                                   db.data_ptr() if db is not None else None, 0, _stream()), "linear_backward")
+        return dx, dw, db
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fusion heads  (models/multimodal.py:62-77)
+# ----------------------------------------------------------------------------------------------------------------------
+class FusionHeads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fi, fc, wf, bf, wi, bi, wc, bc, blend: bool):
+        _need_cuda(fi, fc, wf, bf, wi, bi, wc, bc)
+        fi, fc, wf, bf, wi, bi, wc, bc = (_f32c(t) for t in (fi, fc, wf, bf, wi, bi, wc, bc))
+        n, f = fi.shape
+        c = wf.shape[0]
+        out = torch.empty((3, n, c) if blend else (n, c), device=fi.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_fusion_heads_forward(n, f, c, int(blend), fi.data_ptr(), fc.data_ptr(), wf.data_ptr(), bf.data_ptr(),
+                                                        wi.data_ptr(), bi.data_ptr(), wc.data_ptr(), bc.data_ptr(), out.data_ptr(),
+                                                        _stream()), "fusion_heads_forward")
+        ctx.save_for_backward(fi, fc, wf, wi, wc)
+        ctx.meta = (n, f, c, bool(blend))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fi, fc, wf, wi, wc = ctx.saved_tensors
+        n, f, c, blend = ctx.meta
+        dout = _f32c(dout)
+        dev = fi.device
+        dfi, dfc = torch.empty_like(fi), torch.empty_like(fc)
+        dwf = torch.empty_like(wf)
+        dbf = torch.empty((c,), device=dev, dtype=torch.float32)
+        dwi, dwc = torch.zeros_like(wi), torch.zeros_like(wc)
+        dbi, dbc = torch.zeros((c,), device=dev, dtype=torch.float32), torch.zeros((c,), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_fusion_heads_backward(n, f, c, int(blend), fi.data_ptr(), fc.data_ptr(), wf.data_ptr(), wi.data_ptr(),
+                                                         wc.data_ptr(), dout.data_ptr(), dfi.data_ptr(), dfc.data_ptr(), dwf.data_ptr(),
+                                                         dbf.data_ptr(), dwi.data_ptr(), dbi.data_ptr(), dwc.data_ptr(), dbc.data_ptr(), 0,
+                                                         _stream()), "fusion_heads_backward")
+        if not blend:   # the per-modality heads do not take part in the graph (models/multimodal.py:69)
+            return dfi, dfc, dwf, dbf, None, None, None, None, None
+        return dfi, dfc, dwf, dbf, dwi, dbi, dwc, dbc, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Cox partial likelihood, summed over targets, blended over heads
+# ----------------------------------------------------------------------------------------------------------------------
+class CoxBlend(torch.autograd.Function):
+    """preds (H, N, C); sort_key / weight (N, C) int64 in pycox's (durations, events) positions.  Returns
+    (loss, head_losses) with loss = sum_h head_weights[h] * head_losses[h]."""
+
+    @staticmethod
+    def forward(ctx, preds, sort_key, weight, head_weights):
+        _need_cuda(preds, sort_key, weight, head_weights)
+        preds = _f32c(preds)
+        sort_key = sort_key.to(torch.int64).contiguous()
+        weight = weight.to(torch.int64).contiguous()
+        h, n, c = preds.shape
+        dev = preds.device
+        hw = _f32c(head_weights) if head_weights is not None else None
+        out = torch.empty((1 + h,), device=dev, dtype=torch.float32)
+        grad = torch.empty_like(preds)
+        scratch = torch.empty((4 * n,), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_cox_blend_loss(h, n, c, preds.data_ptr(), sort_key.data_ptr(), weight.data_ptr(),
+                                                  hw.data_ptr() if hw is not None else None, out.data_ptr(), out[1:].data_ptr(),
+                                                  grad.data_ptr(), scratch.data_ptr(), _stream()), "cox_blend_loss")
+        ctx.save_for_backward(grad, hw if hw is not None else torch.ones(h, device=dev))
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None instead of zero tensors (no device sync needed)
+        return out[0], out[1:]
+
+    @staticmethod
+    def backward(ctx, dloss, dheads):
+        grad, hw = ctx.saved_tensors
+        g = None
+        if dloss is not None:
+            g = grad * dloss
+        if dheads is not None:               # d head_losses[h] / d preds = grad[h] / head_weights[h]
+            t = grad * (dheads / hw).view(-1, 1, 1)
+            g = t if g is None else g + t
+        return g, None, None, None

@@ -37,6 +37,7 @@ class NativeBackbone:
         _lib.check(self.L.mmnn_densenet_out_shape(self.plan, *[ctypes.byref(v) for v in c]), "out_shape")
         self.out_shape = (n,) + tuple(v.value for v in c)
         self.device = device
+        self.in_dhw = (d, h, w)
         self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
         self.schema = R.densenet_schema(cfg)
 
@@ -82,3 +83,31 @@ class NativeBackbone:
         assert off >= 0, name
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return self.ws[off:off + n].view(dtype).view(shape)
+
+    def relu_masks(self, flat):
+        """All ReLU branch decisions of the last training forward, keyed like oracle.restatement.densenet_backbone."""
+        n = self.out_shape[0]
+        st = torch.cuda.current_stream().cuda_stream
+        masks = {}
+
+        def fetch(kind, b, l, shape):
+            m = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            _lib.check(self.L.mmnn_densenet_relu_mask(self.plan, flat.data_ptr(), self.ws.data_ptr(), kind, b, l, m.data_ptr(), st), "relu_mask")
+            return m.cpu()
+
+        cfg = self.cfg
+        d0 = [(s - 1) // 2 + 1 for s in self.in_dhw]
+        masks["relu0"] = fetch(0, 0, 0, (n, cfg.init_features, *d0))
+        dims = [(s - 1) // 2 + 1 for s in d0]
+        c = cfg.init_features
+        mid = cfg.bn_size * cfg.growth_rate
+        for b, nl in enumerate(cfg.block_config):
+            for l in range(nl):
+                masks[f"b{b + 1}l{l + 1}r1"] = fetch(1, b, l, (n, c, *dims))
+                masks[f"b{b + 1}l{l + 1}r2"] = fetch(2, b, l, (n, mid, *dims))
+                c += cfg.growth_rate
+            if b != len(cfg.block_config) - 1:
+                masks[f"t{b + 1}"] = fetch(3, b, 0, (n, c, *dims))
+                c //= 2
+                dims = [s // 2 for s in dims]
+        return masks
