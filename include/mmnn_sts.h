@@ -63,6 +63,12 @@ int mmnn_densenet_backward(void* plan, const float* params, const float* x, void
  * Used by the gradient parity tests (ReLU is not differentiable at 0: a reference must take the same branch). */
 int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, int32_t kind, int32_t block, int32_t layer,
                             uint8_t* out, void* stream);
+/* measurement: time every launch of one kernel class with HIP events recorded on the launch stream.
+ * kernel_class 0 none, 1 conv2 fwd, 2 conv2 dgrad, 3 conv2 wgrad, 4 conv1 fwd, 5 conv1 dgrad, 6 conv1 wgrad, 7 stem conv,
+ * 8 stem wgrad; block >= 0 restricts to one dense block (0-based).  read_timer synchronises the recorded events and returns
+ * the accumulated device time and launch count since set_timer. */
+int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
+int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
 /* byte offset of a named workspace region (tests / GradCAM): "x","g","t1","conv0","st_x",... ; -1 if unknown */
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j);
 
@@ -126,6 +132,11 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
  * grad_preds = d loss / d preds.  scratch: 4 * n floats. */
 int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const int64_t* sort_key, const int64_t* weight,
                         const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream);
+
+/* ---- optimizer step over a flat buffer: torch.optim.SGD(momentum, nesterov, weight_decay) as main.py:410-413 uses it.
+ * d = g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr * (nesterov ? d + momentum*buf : buf) */
+int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                  int32_t nesterov, int32_t first_step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,9 +66,27 @@ int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, in
                         static_cast<hipStream_t>(stream));
 }
 
+int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block) {
+  MMNN_REQUIRE(plan, "set_timer: null plan");
+  return plan_set_timer(*static_cast<Plan*>(plan), kernel_class, block);
+}
+
+int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches) {
+  MMNN_REQUIRE(plan, "read_timer: null plan");
+  long n = 0;
+  int rc = plan_read_timer(*static_cast<Plan*>(plan), total_ms, &n);
+  if (launches) *launches = n;
+  return rc;
+}
+
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j) {
   if (!plan || !name) return -1;
   return plan_ws_offset(*static_cast<const Plan*>(plan), name, i, j);
+}
+
+int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                  int32_t nesterov, int32_t first_step, void* stream) {
+  return launch_sgd(params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, first_step, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -178,6 +178,8 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
 void plan_free(Plan& p) {
   if (p.host_jobs) (void)hipHostFree(p.host_jobs);
   p.host_jobs = nullptr;
+  for (hipEvent_t e : p.timer_ev) (void)hipEventDestroy(e);
+  p.timer_ev.clear();
 }
 
 static StatPtr statptr(char* ws, size_t o, int C, int off) {
@@ -267,6 +269,47 @@ static void build_tables(Plan& p, const float* params, float* run, char* ws) {
   p.tab_params = params; p.tab_run = run; p.tab_ws = ws;
 }
 
+// ---- live kernel timing ---------------------------------------------------------------------------------------------
+namespace {
+struct ScopedTimer {   // records a start/stop event pair around one launch when the plan's timer selects it
+  Plan& p; hipStream_t s; bool on;
+  ScopedTimer(Plan& p_, int kind, int block, hipStream_t s_) : p(p_), s(s_), on(false) {
+    if (p.timer_kind != kind || (p.timer_block >= 0 && p.timer_block != block)) return;
+    if (p.timer_used + 2 > p.timer_ev.size()) {
+      if (p.timer_ev.size() >= 4096) return;   // read_timer() was not called for a long time: stop recording
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      p.timer_ev.push_back(a); p.timer_ev.push_back(b);
+    }
+    on = hipEventRecord(p.timer_ev[p.timer_used], s) == hipSuccess;
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(p.timer_ev[p.timer_used + 1], s);
+    p.timer_used += 2;
+  }
+};
+}  // namespace
+
+int plan_set_timer(Plan& p, int kind, int block) {
+  MMNN_REQUIRE(kind >= T_NONE && kind <= T_STEM_WGRAD, "set_timer: unknown kernel class %d", kind);
+  p.timer_kind = kind; p.timer_block = block; p.timer_used = 0; p.timer_ms = 0.0; p.timer_count = 0;
+  return 0;
+}
+
+int plan_read_timer(Plan& p, double* total_ms, long* count) {
+  for (size_t i = 0; i + 1 < p.timer_used; i += 2) {
+    MMNN_HIP(hipEventSynchronize(p.timer_ev[i + 1]));
+    float ms = 0.f;
+    MMNN_HIP(hipEventElapsedTime(&ms, p.timer_ev[i], p.timer_ev[i + 1]));
+    p.timer_ms += ms; p.timer_count += 1;
+  }
+  p.timer_used = 0;
+  if (total_ms) *total_ms = p.timer_ms;
+  if (count) *count = p.timer_count;
+  return 0;
+}
+
 static DropCfg dropcfg(const Plan& p, uint64_t seed, int layer, int training) {
   DropCfg d;
   d.seed = seed; d.layer = layer;
@@ -297,7 +340,8 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
     a.x = x; a.wp = fptr(ws, p.o_pk_conv0); a.out = fptr(ws, p.o_conv0);
     a.st_out = statptr(ws, p.o_st_conv0, c.init_features, 0);
     if (!training) a.st_out.sum = nullptr;
-    if ((rc = launch_stem_conv(a, stream))) return rc;
+    { ScopedTimer t(p, T_STEM_CONV, -1, stream); rc = launch_stem_conv(a, stream); }
+    if (rc) return rc;
     StemPoolArgs q;
     q.N = N; q.C = c.init_features; q.Di = p.D0; q.Hi = p.H0; q.Wi = p.W0; q.Do = p.Db[0]; q.Ho = p.Hb[0]; q.Wo = p.Wb[0];
     q.x = fptr(ws, p.o_conv0);
@@ -325,7 +369,8 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       a.out = fptr(ws, p.o_t1[b][l]); a.out_ns = (long)p.mid * p.Vb[b]; a.out_coff = 0;
       a.st_out = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
       if (!training) a.st_out.sum = nullptr;
-      if ((rc = launch_fprop(a, 1, PRO_BNRELU, EPI_STORE_STATS, stream))) return rc;
+      { ScopedTimer t(p, T_CONV1_FWD, b, stream); rc = launch_fprop(a, 1, PRO_BNRELU, EPI_STORE_STATS, stream); }
+      if (rc) return rc;
       // conv2: ReLU(BN(T1)) -> growth new channels of the concat buffer (+ channel dropout)
       FpropArgs e;
       memset(&e, 0, sizeof(e));
@@ -338,7 +383,8 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       e.drop_out = dropcfg(p, seed, layer_id, training);
       e.st_out = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);
       if (!training) e.st_out.sum = nullptr;
-      if ((rc = launch_fprop(e, 27, PRO_BNRELU, EPI_STORE_STATS, stream))) return rc;
+      { ScopedTimer t(p, T_CONV2_FWD, b, stream); rc = launch_fprop(e, 27, PRO_BNRELU, EPI_STORE_STATS, stream); }
+      if (rc) return rc;
     }
     if (b != nb - 1) {
       const TransOff& t = p.trans[b];
@@ -433,7 +479,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       a.ex = fptr(ws, p.o_t1[b][l]); a.ex_ns = tns; a.ex_coff = 0;
       a.ebn = bn2;
       a.dbeta = dg2.sum; a.dgamma = dg2.sq;
-      if ((rc = launch_fprop(a, 27, PRO_GRAD, EPI_MASK_STORE, stream))) return rc;
+      { ScopedTimer t(p, T_CONV2_DGRAD, b, stream); rc = launch_fprop(a, 27, PRO_GRAD, EPI_MASK_STORE, stream); }
+      if (rc) return rc;
       // conv2 weight gradient
       WgradArgs w2;
       memset(&w2, 0, sizeof(w2));
@@ -445,7 +492,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
       w2.bn = bn2;
       w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
-      if ((rc = launch_wgrad(w2, 27, PRO_BNRELU, stream))) return rc;
+      { ScopedTimer t(p, T_CONV2_WGRAD, b, stream); rc = launch_wgrad(w2, 27, PRO_BNRELU, stream); }
+      if (rc) return rc;
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
@@ -467,7 +515,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       d.ebn = bn1;
       d.dbeta = dg1.sum; d.dgamma = dg1.sq;
       d.s_acc = sptr(b, 0);
-      if ((rc = launch_fprop(d, 1, PRO_GRAD, EPI_MASK_ACCUM, stream))) return rc;
+      { ScopedTimer t(p, T_CONV1_DGRAD, b, stream); rc = launch_fprop(d, 1, PRO_GRAD, EPI_MASK_ACCUM, stream); }
+      if (rc) return rc;
       // conv1 weight gradient
       WgradArgs w1;
       memset(&w1, 0, sizeof(w1));
@@ -479,7 +528,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
       w1.bn = bn1;
       w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
-      if ((rc = launch_wgrad(w1, 1, PRO_BNRELU, stream))) return rc;
+      { ScopedTimer t(p, T_CONV1_WGRAD, b, stream); rc = launch_wgrad(w1, 1, PRO_BNRELU, stream); }
+      if (rc) return rc;
     }
     if (b > 0) {
       const int pb = b - 1;
@@ -541,7 +591,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w.gr.inv_count = 1.0 / cnt0;
       w.gr.eps = c.eps;
       w.slab = fptr(ws, p.o_sl_conv0); w.slab_stride = (long)c.in_channels * c.init_features * 352; w.nsplit = p.ns_conv0;
-      if ((rc = launch_stem_wgrad(w, stream))) return rc;
+      { ScopedTimer t(p, T_STEM_WGRAD, -1, stream); rc = launch_stem_wgrad(w, stream); }
+      if (rc) return rc;
     }
   }
   return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), p.n_grad_jobs, p.max_grad, grad_params, accumulate, stream);

@@ -64,7 +64,17 @@ struct Plan {
   // cached identity of the buffers the tables were built for
   const float* tab_params = nullptr; float* tab_run = nullptr; char* tab_ws = nullptr;
   int n_run_jobs = 0, n_pack_jobs = 0, n_grad_jobs = 0; long max_pack = 0, max_grad = 0;
+  // optional live timing of one kernel class with HIP events (bench.py roofline leg)
+  int timer_kind = 0, timer_block = -1;            // kind: see TimerKind; block < 0: every block
+  std::vector<hipEvent_t> timer_ev;                // start/stop pairs recorded since the last read
+  size_t timer_used = 0;
+  double timer_ms = 0.0; long timer_count = 0;
 };
+
+enum TimerKind { T_NONE = 0, T_CONV2_FWD = 1, T_CONV2_DGRAD = 2, T_CONV2_WGRAD = 3, T_CONV1_FWD = 4, T_CONV1_DGRAD = 5,
+                 T_CONV1_WGRAD = 6, T_STEM_CONV = 7, T_STEM_WGRAD = 8 };
+int plan_set_timer(Plan& p, int kind, int block);
+int plan_read_timer(Plan& p, double* total_ms, long* count);
 
 int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W);
 void plan_free(Plan& p);

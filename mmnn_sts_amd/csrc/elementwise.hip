@@ -241,4 +241,42 @@ int launch_finalize(const GradJob* jobs_dev, int njobs, long max_count, float* g
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float mom, float wd, int nesterov, int first) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0)) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 bv = first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(buf + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = fmaf(wd, pv[e], gv[e]);
+        const float b = first ? d : fmaf(mom, bv[e], d);
+        bv[e] = b;
+        d = nesterov ? fmaf(mom, b, d) : b;
+        pv[e] = fmaf(-lr, d, pv[e]);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv;
+      *reinterpret_cast<f32x4*>(buf + i) = bv;
+    } else {
+      for (long j = i; j < n && j < i + 4; ++j) {
+        float d = fmaf(wd, p[j], g[j]);
+        const float b = first ? d : fmaf(mom, buf[j], d);
+        buf[j] = b;
+        d = nesterov ? fmaf(mom, b, d) : b;
+        p[j] = fmaf(-lr, d, p[j]);
+      }
+    }
+  }
+}
+
+int launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay, int nesterov, int first_step,
+               hipStream_t stream) {
+  MMNN_REQUIRE(p && g && buf && n > 0, "sgd: bad arguments");
+  int gx = cdiv(n, 1024);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(sgd_kernel, dim3(gx), dim3(256), 0, stream, p, g, buf, n, lr, momentum, weight_decay, nesterov, first_step);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace mmnn

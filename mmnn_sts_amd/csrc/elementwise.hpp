@@ -79,4 +79,8 @@ struct GradJob {
 };
 int launch_finalize(const GradJob* jobs_dev, int njobs, long max_count, float* grad, int accumulate, hipStream_t stream);
 
+// ---- SGD with momentum / Nesterov / weight decay over a flat buffer (torch.optim.SGD semantics, main.py:410-413)
+int launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay, int nesterov, int first_step,
+               hipStream_t stream);
+
 }  // namespace mmnn

@@ -36,7 +36,7 @@ class GradientBlender:
             return ops.CoxBlend.apply(preds, events, durations, weights)     # (blend, head_losses)
         hl = torch.stack([self.surv_criterion(self.loss_function, preds[i, ...], events, durations, preds.device)
                           for i in range(preds.shape[0])], dim=0)
-        return (None if weights is None else self.reduce(weights * hl)), hl
+        return (None if weights is None else torch.sum(weights * hl)), hl
 
     def computeLossSurv(self, preds, events, durations, reduceToHeads=False):
         if self.weights is None:
