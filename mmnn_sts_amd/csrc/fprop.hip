@@ -4,10 +4,10 @@
 
 namespace mmnn {
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
 static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
-  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
-  auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
+  auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
   const size_t smem = C::smem_bytes(a.Cin);
   MMNN_REQUIRE(smem <= 160 * 1024, "fprop: %zu bytes of LDS needed (Cin=%d) exceeds 160 KiB", smem, a.Cin);
   static size_t configured = 0;
@@ -25,24 +25,30 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// Tile selection.  Template arguments: <TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>; a block computes
+// (WM*MT*32) output rows x (WN*NT*32) voxels with WM*WN*KS waves, KS wave groups splitting each channel chunk.
+// Small extents get small voxel tiles + a deep K-split so that the late dense blocks (8^3, 4^3 voxels) still put
+// hundreds of waves on the chip instead of a dozen.
 template <int TAPS, int PRO, int EPI>
 static int dispatch(const FpropArgs& a, hipStream_t s) {
   const long V = (long)a.D * a.H * a.W;
   if (TAPS == 1) {
-    const long big_blocks = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
-    if (big_blocks >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 2, 16, 1, 1, 128>(a, s);
-    return launch_cfg<1, PRO, EPI, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
+    const long blocks_a = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
+    const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
+    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
+    if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
+    return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 32, 1, 1, 32>(a, s);
   }
   if (a.M <= 32) {
-    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 2, 8, 2, 4, 32>(a, s);
-    if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 4, 1, 2, 8, 2, 8, 16>(a, s);
-    if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 2, 1, 1, 8, 2, 4, 8>(a, s);
-    return launch_cfg<27, PRO, EPI, 1, 2, 1, 1, 8, 4, 4, 4>(a, s);
+    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32>(a, s);
+    if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 2, 4, 1, 1, 16, 1, 4, 16>(a, s);
+    if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
+    return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
   }
-  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 4, 1, 4, 32>(a, s);
-  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 4, 2, 4, 16>(a, s);
-  if (a.W > 4) return launch_cfg<27, PRO, EPI, 2, 2, 2, 1, 4, 2, 4, 8>(a, s);
-  return launch_cfg<27, PRO, EPI, 2, 2, 2, 1, 4, 4, 4, 4>(a, s);
+  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);
+  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
+  if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);
+  return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 2, 4, 4>(a, s);
 }
 
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream) {

@@ -43,9 +43,9 @@ int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t str
 
 #if defined(__HIPCC__)
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
 struct FpropCfg {
-  static constexpr int NWAVES = WM * WN;
+  static constexpr int NWAVES = WM * WN * KS;          // KS wave groups split the channel (reduction) axis of every chunk
   static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int M_B = WM * MT * 32;
   static constexpr int V_B = WN * NT * 32;
@@ -56,11 +56,14 @@ struct FpropCfg {
   static constexpr int NCOEF = (PRO == PRO_BNRELU) ? 2 : (PRO == PRO_GRAD ? 3 : 0);
   static constexpr int ECOEF = 6 + 2 * WN;   // per output row: a, b, mean, rstd, gamma, dropscale, then per-wave partial sums
   static_assert(TD * TH * TW == V_B, "tile volume must equal the block's voxel count");
-  static_assert(KC % 2 == 0, "channel chunk must be even (two channels per MFMA)");
+  static_assert(KC % 2 == 0 && (KC / 2) % KS == 0, "channel-pair count of a chunk must be a multiple of the K-split");
+  static constexpr int STAGE = KC * XS + KC * TAPS * M_B;                       // floats: activations + weights of a chunk
+  static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
+  static constexpr int BUF = STAGE > REDN ? STAGE : REDN;
   static size_t smem_bytes(int Cin) {
     int cpad = ((Cin + KC - 1) / KC) * KC;
     size_t ncoef = ((size_t)NCOEF * cpad + 3) & ~(size_t)3;   // keep the staging buffers 16-byte aligned
-    return sizeof(float) * (ncoef + (size_t)KC * XS + (size_t)KC * TAPS * M_B + (size_t)ECOEF * M_B);
+    return sizeof(float) * (ncoef + (size_t)BUF + (size_t)ECOEF * M_B);
   }
 };
 
@@ -71,21 +74,22 @@ __device__ __forceinline__ float pro_apply(const float* coef, int cpad, int c, f
   return x0;
 }
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int MT, int NT, int KC, int TD, int TH, int TW>
-__global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
-  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, MT, NT, KC, TD, TH, TW>;
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
+__global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs a) {
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
   constexpr int NTHREADS = C::NTHREADS, M_B = C::M_B, V_B = C::V_B, RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
+  const int kg = wave / (WM * WN);                      // K-split group of this wave
+  const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
   const int V = a.D * a.H * a.W;
   const int cpad = ((a.Cin + KC - 1) / KC) * KC;
 
   float* coef = smem;
   float* Xs = coef + ((C::NCOEF * cpad + 3) & ~3);
   float* Ws = Xs + KC * XS;
-  float* ecoef = Ws + KC * TAPS * M_B;
+  float* ecoef = Xs + C::BUF;
 
   // ---- which tile ----
   int n, d0 = 0, h0 = 0, w0 = 0, v0 = 0;
@@ -292,18 +296,19 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
 
     // ================= MFMA over the chunk =================
     {
-      const float* xb = Xs + half * XS;
-      const float* wb = Ws + half * TAPS * M_B + wm * MT * 32 + l31;
+      const float* xb = Xs + (2 * kg + half) * XS;
+      const float* wb = Ws + (2 * kg + half) * TAPS * M_B + wm * MT * 32 + l31;
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
+      for (int jj = 0; jj < KC / 2 / KS; ++jj) {
+        constexpr int PAIR = 2 * KS;               // channel distance between consecutive pairs of one wave group
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
           const int toff = (TAPS == 27) ? (((tap / 9) * HS + (tap / 3) % 3) * RS + tap % 3) : 0;
           float av[MT], bv[NT];
 #pragma unroll
-          for (int i = 0; i < MT; ++i) av[i] = wb[(2 * kk * TAPS + tap) * M_B + i * 32];
+          for (int i = 0; i < MT; ++i) av[i] = wb[(jj * PAIR * TAPS + tap) * M_B + i * 32];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bv[j] = xb[2 * kk * XS + pos[j] + toff];
+          for (int j = 0; j < NT; ++j) bv[j] = xb[jj * PAIR * XS + pos[j] + toff];
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -312,6 +317,31 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
       }
     }
     __syncthreads();
+  }
+
+  // ================= cross-group reduction of the accumulators (K-split) =================
+  if (KS > 1) {
+    float* rbuf = Xs;   // staging buffers are free after the last barrier
+    const int slot = (wm * WN + wn) * MT * NT;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rbuf[(((kg - 1) * WM * WN * MT * NT + slot + i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KS; ++g)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += rbuf[(((g - 1) * WM * WN * MT * NT + slot + i * NT + j) * 16 + r) * 64 + lane];
+    }
   }
 
   // ================= epilogue =================
@@ -337,6 +367,7 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
     }
   }
 
+  if (kg == 0) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float s0[16], s1[16];
@@ -384,6 +415,7 @@ __global__ void __launch_bounds__(WM* WN * 64) fprop_kernel(const FpropArgs a) {
         red1[wn * M_B + ml] = r1;
       }
     }
+  }
   }
   if (want_sums) {
     __syncthreads();
