@@ -1,5 +1,7 @@
 // Host-side dispatch of the implicit-GEMM convolution template (fprop.hpp): picks a tile shape from the
 // spatial extent and the number of output rows, validates every shape the kernel indexes with, and launches.
+#include <stdlib.h>
+
 #include "fprop.hpp"
 
 namespace mmnn {
@@ -8,8 +10,12 @@ template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, in
 static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
   auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
-  const size_t smem = C::smem_bytes(a.Cin);
+  size_t smem = C::smem_bytes(a.Cin);
   MMNN_REQUIRE(smem <= 160 * 1024, "fprop: %zu bytes of LDS needed (Cin=%d) exceeds 160 KiB", smem, a.Cin);
+  {
+    static const char* env = getenv("MMNN_FPROP_MIN_SMEM");   // experiment knob: force fewer blocks per CU
+    if (env) { size_t v = (size_t)atol(env); if (v > smem && v <= 160 * 1024) smem = v; }
+  }
   static size_t configured = 0;
   if (smem > configured) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

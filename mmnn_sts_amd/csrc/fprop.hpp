@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
   float* ecoef = Xs + C::BUF;
 
   // ---- which tile ----
-  int n, d0 = 0, h0 = 0, w0 = 0, v0 = 0;
+  int n, d0 = 0, h0 = 0, w0 = 0, v0_ = 0;
   {
     int b = blockIdx.x;
     if (TAPS == 27) {
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
       n = b;
     } else {
       const int nt = (V + V_B - 1) / V_B;
-      v0 = (b % nt) * V_B;
+      v0_ = (b % nt) * V_B;
       n = b / nt;
     }
   }
@@ -169,6 +169,154 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
   const bool vecx = al_x && ((TAPS == 27) ? ((a.W & 3) == 0) : ((V & 3) == 0));
   const bool vecw = ((a.w_ld & 3) == 0) && ((a.M & 3) == 0) && (((uintptr_t)a.w & 15) == 0);
 
+  // ---- MFMA over one staged chunk.  The operand reads of step s+1 are issued before the MFMAs of step s (two register
+  // sets), so that the LDS latency hides behind the matrix pipe even with a single wave per SIMD. ----
+  auto mfma_chunk = [&]() {
+    const float* xb = Xs + (2 * kg + half) * XS;
+    const float* wb = Ws + (2 * kg + half) * TAPS * M_B + wm * MT * 32 + l31;
+    constexpr int PAIR = 2 * KS;                 // channel distance between consecutive pairs of one wave group
+    constexpr int NSTEP = (KC / 2 / KS) * TAPS;
+    auto rd = [&](int st, float (&av)[MT], float (&bv)[NT]) {
+      const int jj = st / TAPS, tap = st % TAPS;
+      const int toff = (TAPS == 27) ? (((tap / 9) * HS + (tap / 3) % 3) * RS + tap % 3) : 0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = wb[(jj * PAIR * TAPS + tap) * M_B + i * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = xb[jj * PAIR * XS + pos[j] + toff];
+    };
+    auto mm = [&](const float (&av)[MT], const float (&bv)[NT]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    rd(0, a0, b0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st += 2) {
+      if (st + 1 < NSTEP) rd(st + 1, a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // DS reads of the next step first ...
+      mm(a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);   // ... then this step's MFMAs
+      if (st + 2 < NSTEP) rd(st + 2, a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+      if (st + 1 < NSTEP) mm(a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+    }
+  };
+
+  if (vecx && vecw) {
+    // ===== fast path: 16-byte staging through registers, software-pipelined.  The global loads of chunk k+1 are issued
+    // (all at once) before the MFMA loop of chunk k and only waited for when they are written to LDS afterwards. =====
+    constexpr int ROWS = (TAPS == 27) ? KC * DS * HS : KC;                   // staged rows (channel x halo row)
+    constexpr int VPR = (TAPS == 27) ? TW / 4 : V_B / 4;                      // 16-byte items per row
+    constexpr int XV_ITEMS = ROWS * VPR;
+    constexpr int XH_ITEMS = (TAPS == 27) ? ROWS * 2 : 0;                     // halo columns: one float each
+    constexpr int W_ITEMS = KC * TAPS * (M_B / 4);
+    constexpr int XV_IT = (XV_ITEMS + NTHREADS - 1) / NTHREADS, XH_IT = (XH_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr bool GR = (PRO == PRO_GRAD);
+    f32x4 xv0[XV_IT], xv1[GR ? XV_IT : 1], wr[W_IT];
+    float xh0[XH_IT > 0 ? XH_IT : 1], xh1[(GR && XH_IT > 0) ? XH_IT : 1];
+    unsigned okv = 0, okh = 0;
+
+    // row r of the staged box -> (local channel, offset of the row start in LDS, global row offset, row validity)
+    auto row_info = [&](int r, int c0, int& cl, int& lrow, long& gro, bool& rowok) {
+      if (TAPS == 27) {
+        const int hy = r % HS, dz = (r / HS) % DS;
+        cl = r / (HS * DS);
+        const int d = d0 + dz - 1, h = h0 + hy - 1;
+        rowok = (c0 + cl < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
+        gro = (long)(c0 + cl) * V + ((long)d * a.H + h) * a.W;
+        lrow = cl * XS + (dz * HS + hy) * RS;
+      } else {
+        cl = r;
+        rowok = c0 + cl < a.Cin;
+        gro = (long)(c0 + cl) * V;
+        lrow = cl * XS;
+      }
+    };
+
+    // NOTE: every load below is UNCONDITIONAL (out-of-range items read element 0 of their tensor and are zeroed when
+    // they are written to LDS).  A load under a divergent `if` makes hipcc branch around it and wait vmcnt(0) at the join,
+    // which serialises the whole batch (one memory round trip per item instead of one per chunk).
+    auto load_chunk = [&](int c0) {
+      okv = 0; okh = 0;
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it / VPR, c0, cl, lrow, gro, rowok);
+        const int col = ((TAPS == 27) ? w0 : v0_) + 4 * (it % VPR);
+        const bool ok = (it < XV_ITEMS) && rowok && col < ((TAPS == 27) ? a.W : V);
+        const long off = ok ? gro + col : 0;
+        okv |= (ok ? 1u : 0u) << i;
+        xv0[i] = *reinterpret_cast<const f32x4*>(in0n + off);
+        if (GR) xv1[i] = *reinterpret_cast<const f32x4*>(in1n + off);
+      }
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it >> 1, c0, cl, lrow, gro, rowok);
+        const int w = (it & 1) ? w0 + TW : w0 - 1;
+        const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
+        const long off = ok ? gro + w : 0;
+        okh |= (ok ? 1u : 0u) << i;
+        xh0[i] = in0n[off];
+        if (GR) xh1[i] = in1n[off];
+      }
+      const long kbase = (long)c0 * TAPS, klim = (long)a.Cin * TAPS;
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        const int q = it % (M_B / 4), kr = it / (M_B / 4);
+        const bool ok = (it < W_ITEMS) && (kbase + kr < klim) && (m0 + 4 * q < a.M);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (ok ? (kbase + kr) * a.w_ld + m0 + 4 * q : 0));
+        wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+
+    auto store_chunk = [&](int c0) {
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < XV_ITEMS) {
+          int cl, lrow; long gro; bool rowok;
+          row_info(it / VPR, c0, cl, lrow, gro, rowok);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c0 + cl, xv0[i][e], GR ? xv1[i][e] : 0.f);
+          if (!((okv >> i) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(Xs + lrow + ((TAPS == 27) ? 4 : 0) + 4 * (it % VPR)) = o;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < XH_ITEMS) {
+          int cl, lrow; long gro; bool rowok;
+          row_info(it >> 1, c0, cl, lrow, gro, rowok);
+          const float o = pro_apply<PRO>(coef, cpad, c0 + cl, xh0[i], GR ? xh1[i] : 0.f);
+          Xs[lrow + ((it & 1) ? TW + 4 : 3)] = ((okh >> i) & 1u) ? o : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + 4 * it) = wr[i];
+      }
+    };
+
+    load_chunk(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+      store_chunk(c0);
+      __syncthreads();
+      if (c0 + KC < a.Cin) load_chunk(c0 + KC);
+      mfma_chunk();
+      __syncthreads();
+    }
+  } else {
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
     // ================= stage activations =================
     if (TAPS == 27) {
@@ -236,7 +384,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
           const int q = it % (V_B / 4);
           const int cl = it / (V_B / 4);
           const int c = c0 + cl;
-          const int v = v0 + 4 * q;
+          const int v = v0_ + 4 * q;
           f32x4 o = {0.f, 0.f, 0.f, 0.f};
           if (c < a.Cin && v < V) {
             const long g = (long)c * V + v;
@@ -254,7 +402,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
           const int q = it % V_B;
           const int cl = it / V_B;
           const int c = c0 + cl;
-          const int v = v0 + q;
+          const int v = v0_ + q;
           float o = 0.f;
           if (c < a.Cin && v < V) {
             const long g = (long)c * V + v;
@@ -293,30 +441,9 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
       }
     }
     __syncthreads();
-
-    // ================= MFMA over the chunk =================
-    {
-      const float* xb = Xs + (2 * kg + half) * XS;
-      const float* wb = Ws + (2 * kg + half) * TAPS * M_B + wm * MT * 32 + l31;
-#pragma unroll
-      for (int jj = 0; jj < KC / 2 / KS; ++jj) {
-        constexpr int PAIR = 2 * KS;               // channel distance between consecutive pairs of one wave group
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int toff = (TAPS == 27) ? (((tap / 9) * HS + (tap / 3) % 3) * RS + tap % 3) : 0;
-          float av[MT], bv[NT];
-#pragma unroll
-          for (int i = 0; i < MT; ++i) av[i] = wb[(jj * PAIR * TAPS + tap) * M_B + i * 32];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bv[j] = xb[jj * PAIR * XS + pos[j] + toff];
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
+    mfma_chunk();
     __syncthreads();
+  }
   }
 
   // ================= cross-group reduction of the accumulators (K-split) =================
@@ -362,7 +489,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
       vok[j] = d < a.D && h < a.H && w < a.W;
       vox[j] = ((long)d * a.H + h) * a.W + w;
     } else {
-      vox[j] = v0 + t;
+      vox[j] = v0_ + t;
       vok[j] = vox[j] < V;
     }
   }

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
     __syncthreads();
     // ---- stage input planes d_in = 2*(do0+dz) + kd - 3 ----
     const int items = a.Cin * SC_TD * SC_ROWS * 69;
+#pragma unroll 8
     for (int it = tid; it < items; it += 256) {
       const int ci = it % 69;
       int row = it / 69;
@@ -60,10 +61,9 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
       const int dz = row % SC_TD;
       const int c = row / SC_TD;
       const int d = 2 * (do0 + dz) + kd - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
-      float v = 0.f;
-      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = xn[(long)c * Vi + ((long)d * a.H + h) * a.W + w];
-      Xs[c * SC_CS + (dz * SC_ROWS + r) * SC_RS + (ci & 1) * SC_PO + (ci >> 1)] = v;
+      const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      const float v = xn[ok ? (long)c * Vi + ((long)d * a.H + h) * a.W + w : 0];   // unconditional load, clamped address
+      Xs[c * SC_CS + (dz * SC_ROWS + r) * SC_RS + (ci & 1) * SC_PO + (ci >> 1)] = ok ? v : 0.f;
     }
     // ---- stage this kd's weight rows ----
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wp + (long)kd * krows * 64);
@@ -344,27 +344,24 @@ __global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradA
     const int n = b;
     const float* xc = a.x + ((long)n * a.Cin + c) * Vi;
     __syncthreads();
-#pragma unroll 4
+#pragma unroll 5
     for (int it = tid; it < SW_PLANES * SW_ROWS * 37; it += SW_THREADS) {
       const int ci = it % 37;
       const int r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
       const int d = 2 * do0 + pl - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
-      float v = 0.f;
-      if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = xc[((long)d * a.H + h) * a.W + w];
-      Xs[pl * SW_PS + r * SW_RS + ci] = v;
+      const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      const float v = xc[ok ? ((long)d * a.H + h) * a.W + w : 0];
+      Xs[pl * SW_PS + r * SW_RS + ci] = ok ? v : 0.f;
     }
-#pragma unroll 2
+#pragma unroll 6
     for (int it = tid; it < 64 * 64; it += SW_THREADS) {
       const int t = it & 63, m = it >> 6;
       const int wx = t % SW_TW, hy = (t / SW_TW) % SW_TH, dz = t / (SW_TW * SW_TH);
       const int d = do0 + dz, h = ho0 + hy, w = wo0 + wx;
-      float o = 0.f;
-      if (m < a.M && d < a.Do && h < a.Ho && w < a.Wo) {
-        const long g = ((long)n * a.M + m) * Vo + ((long)d * a.Ho + h) * a.Wo + w;
-        o = fmaf(gcoef[m], a.dz[g], fmaf(gcoef[64 + m], a.y[g], gcoef[128 + m]));
-      }
-      Ys[m * SW_YS + t] = o;
+      const bool ok = m < a.M && d < a.Do && h < a.Ho && w < a.Wo;
+      const long g = ok ? ((long)n * a.M + m) * Vo + ((long)d * a.Ho + h) * a.Wo + w : 0;
+      const float o = fmaf(gcoef[m], a.dz[g], fmaf(gcoef[64 + m], a.y[g], gcoef[128 + m]));
+      Ys[m * SW_YS + t] = ok ? o : 0.f;
     }
     __syncthreads();
 #pragma unroll 1

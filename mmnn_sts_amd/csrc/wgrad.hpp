@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
     const float* g1n = a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
     // ---- stage the input halo box (zero padded AFTER the activation) ----
     constexpr int XITEMS = 32 * DS * HS * RS;
-#pragma unroll 4
+#pragma unroll 8
     for (int it = tid; it < XITEMS; it += NTHREADS) {
       const int q = it % RS;
       int row = it / RS;
@@ -121,12 +121,11 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
       const int dz = row % DS;
       const int cl = row / DS;
       const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + q - 1;
-      float o = 0.f;
-      if (c0 + cl < a.Cin && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) {
-        const float x = xn[(long)cl * V + ((long)d * a.H + h) * a.W + w];
-        o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], x, xcoef[32 + cl]), 0.f) : x;
-      }
-      Xs[cl * XS + (dz * HS + hy) * RS + q] = o;
+      // unconditional load from a clamped address (a load under a divergent branch costs one memory round trip EACH)
+      const bool ok = c0 + cl < a.Cin && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      const float x = xn[ok ? (long)cl * V + ((long)d * a.H + h) * a.W + w : 0];
+      const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], x, xcoef[32 + cl]), 0.f) : x;
+      Xs[cl * XS + (dz * HS + hy) * RS + q] = ok ? o : 0.f;
     }
     // ---- stage dOut for the tile's 64 voxels ----
 #pragma unroll 4
@@ -134,12 +133,10 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
       const int t = it & 63, m = it >> 6;
       const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
       const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
-      float o = 0.f;
-      if (m < a.M && d < a.D && h < a.H && w < a.W) {
-        const long g = (long)m * V + ((long)d * a.H + h) * a.W + w;
-        o = fmaf(gcoef[m], g0n[g], fmaf(gcoef[32 + m], g1n[g], gcoef[64 + m]));
-      }
-      Ys[m * YS + t] = o;
+      const bool ok = m < a.M && d < a.D && h < a.H && w < a.W;
+      const long g = ok ? (long)m * V + ((long)d * a.H + h) * a.W + w : 0;
+      const float o = fmaf(gcoef[m], g0n[g], fmaf(gcoef[32 + m], g1n[g], gcoef[64 + m]));
+      Ys[m * YS + t] = ok ? o : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -233,32 +230,25 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
     const float* g0n = a.g0 + (long)n * a.g0_ns + (long)(a.g0_coff + m0) * V;
     const float* g1n = a.g1 + (long)n * a.g1_ns + (long)(a.g1_coff + m0) * V;
     if (vec) {
-#pragma unroll 2
+#pragma unroll 4
       for (int it = tid; it < 128 * (VK / 4); it += NTHREADS) {
         const int q = it % (VK / 4), m = it / (VK / 4);
         const int v = v0 + 4 * q;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + m < a.M && v < V) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(g0n + (long)m * V + v);
-          const f32x4 g1 = *reinterpret_cast<const f32x4*>(g1n + (long)m * V + v);
+        const bool ok = m0 + m < a.M && v < V;
+        const long go = ok ? (long)m * V + v : 0;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g0n + go);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(g1n + go);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaf(gcoef[m], g0[e], fmaf(gcoef[128 + m], g1[e], gcoef[256 + m]));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[m * S + 4 * q + e] = o[e];
+        for (int e = 0; e < 4; ++e) As[m * S + 4 * q + e] = ok ? fmaf(gcoef[m], g0[e], fmaf(gcoef[128 + m], g1[e], gcoef[256 + m])) : 0.f;
       }
-#pragma unroll 2
+#pragma unroll 4
       for (int it = tid; it < CB * (VK / 4); it += NTHREADS) {
         const int q = it % (VK / 4), c = it / (VK / 4);
         const int v = v0 + 4 * q;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + c < a.Cin && v < V) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(xn + (long)c * V + v);
+        const bool ok = c0 + c < a.Cin && v < V;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xn + (ok ? (long)c * V + v : 0));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[c], x[e], xcoef[CB + c]), 0.f) : x[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[c * S + 4 * q + e] = o[e];
+        for (int e = 0; e < 4; ++e) Bs[c * S + 4 * q + e] = ok ? ((PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[c], x[e], xcoef[CB + c]), 0.f) : x[e]) : 0.f;
       }
     } else {
 #pragma unroll 2
