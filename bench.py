@@ -47,6 +47,20 @@ def synth_batch(device, rank, n=2, s=128):
     return {"image": image, "clinical": clinical}, events, durations
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_traffic.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied); None when
+    no such measurement is committed.  Counters cannot be read from inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def host_cores() -> int:
     """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box gives one GPU's
     share of the host, not every core `os.cpu_count()` reports)."""
@@ -200,7 +214,7 @@ def main():
             ach = flop / avg_s / 1e12 if avg_s > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "kernel": "fprop_kernel<27,...> conv2 3x3x3 128->32 forward, dense block 1",
                                "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                               "traffic": None, "launches_timed": int(cnt.value), "avg_us": avg_s * 1e6,
+                               "traffic": measured_traffic(), "launches_timed": int(cnt.value), "avg_us": avg_s * 1e6,
                                "flop_per_launch": flop}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.micro_batch, a.size)
