@@ -92,6 +92,159 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // ---- MFMA over one staged tile: 32 k-steps (2 voxels each) x 3 taps; operand reads of step s+1 issued before the
+  // MFMAs of step s (two register sets) ----
+  auto mfma_tile = [&]() {
+    auto rd = [&](int s, float& av, float (&bv)[3]) {
+      const int wx = s % TW, hy = (s / TW) % TH, dz = s / (TW * TH);
+      const int p0 = (dz * HS + hy) * RS + wx;
+      av = yl[s];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) bv[kw] = xl[p0 + kw];
+    };
+    auto mm = [&](float av, const float (&bv)[3]) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kw], acc[kw], 0, 0, 0);
+    };
+    float a0, a1, b0[3], b1[3];
+    rd(0, a0, b0);
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+      rd(s + 1, a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      mm(a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      if (s + 2 < 32) rd(s + 2, a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      mm(a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    }
+  };
+  auto tile_origin = [&](int tile, int& n, int& d0, int& h0, int& w0) {
+    int b = tile;
+    w0 = (b % nw) * TW; b /= nw;
+    h0 = (b % nh) * TH; b /= nh;
+    d0 = (b % nd) * TD; b /= nd;
+    n = b;
+  };
+  const bool vec = ((a.W & 3) == 0) && ((TW & 3) == 0) && ((((uintptr_t)a.x | (uintptr_t)a.g0 | (uintptr_t)a.g1) & 15) == 0) && ((V & 3) == 0);
+
+  if (vec) {
+    // ===== fast path: 16-byte unconditional loads of tile t+1 issued before the MFMA loop of tile t (register staging) =====
+    constexpr int ROWS = 32 * DS * HS, VPR = TW / 4;
+    constexpr int XV_ITEMS = ROWS * VPR, XH_ITEMS = ROWS * 2, Y_ITEMS = 32 * 16;
+    constexpr int XV_IT = (XV_ITEMS + NTHREADS - 1) / NTHREADS, XH_IT = (XH_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int Y_IT = (Y_ITEMS + NTHREADS - 1) / NTHREADS;
+    f32x4 xv[XV_IT], y0[Y_IT], y1[Y_IT];
+    float xh[XH_IT];
+    unsigned okv = 0, okh = 0, oky = 0;
+    auto row_info = [&](int r, int d0, int h0, int& cl, int& lrow, long& gro, bool& rowok) {
+      const int hy = r % HS, dz = (r / HS) % DS;
+      cl = r / (HS * DS);
+      const int d = d0 + dz - 1, h = h0 + hy - 1;
+      rowok = (c0 + cl < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
+      gro = (long)cl * V + ((long)d * a.H + h) * a.W;
+      lrow = cl * XS + (dz * HS + hy) * RS;
+    };
+    auto load_tile = [&](int tile) {
+      int n, d0, h0, w0;
+      tile_origin(tile, n, d0, h0, w0);
+      const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
+      const float* g0n = a.g0 + (long)n * a.g0_ns + (long)a.g0_coff * V;
+      const float* g1n = a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
+      okv = okh = oky = 0;
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it / VPR, d0, h0, cl, lrow, gro, rowok);
+        const int w = w0 + 4 * (it % VPR);
+        const bool ok = (it < XV_ITEMS) && rowok && w < a.W;
+        okv |= (ok ? 1u : 0u) << i;
+        xv[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? gro + w : 0));
+      }
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it >> 1, d0, h0, cl, lrow, gro, rowok);
+        const int w = (it & 1) ? w0 + TW : w0 - 1;
+        const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
+        okh |= (ok ? 1u : 0u) << i;
+        xh[i] = xn[ok ? gro + w : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < Y_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        const int m = it >> 4, t = 4 * (it & 15);
+        const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+        const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+        const bool ok = (it < Y_ITEMS) && m < a.M && d < a.D && h < a.H && w < a.W;
+        const long g = ok ? (long)m * V + ((long)d * a.H + h) * a.W + w : 0;
+        oky |= (ok ? 1u : 0u) << i;
+        y0[i] = *reinterpret_cast<const f32x4*>(g0n + g);
+        y1[i] = *reinterpret_cast<const f32x4*>(g1n + g);
+      }
+    };
+    auto store_tile = [&](int tile) {
+      int n, d0, h0, w0;
+      tile_origin(tile, n, d0, h0, w0);
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < XV_ITEMS) {
+          int cl, lrow; long gro; bool rowok;
+          row_info(it / VPR, d0, h0, cl, lrow, gro, rowok);
+          const bool ok = (okv >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xv[i][e], xcoef[32 + cl]), 0.f) : xv[i][e];
+            Xs[lrow + 1 + 4 * (it % VPR) + e] = ok ? o : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < XH_ITEMS) {
+          int cl, lrow; long gro; bool rowok;
+          row_info(it >> 1, d0, h0, cl, lrow, gro, rowok);
+          const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xh[i], xcoef[32 + cl]), 0.f) : xh[i];
+          Xs[lrow + ((it & 1) ? TW + 1 : 0)] = ((okh >> i) & 1u) ? o : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < Y_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < Y_ITEMS) {
+          const int m = it >> 4, t = 4 * (it & 15);
+          const bool ok = (oky >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            Ys[m * YS + t + e] = ok ? fmaf(gcoef[m], y0[i][e], fmaf(gcoef[32 + m], y1[i][e], gcoef[64 + m])) : 0.f;
+        }
+      }
+    };
+    int cur_n = -1;
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      int n, d0, h0, w0;
+      tile_origin(tile, n, d0, h0, w0);
+      if (n != cur_n) {   // dropout scale depends on the sample: refresh the dOut coefficients (previous tile fully consumed)
+        if (tid < 32) {
+          const float sc = drop_scale(a.drop, n, tid);
+          gcoef[tid] = gbase[tid] * sc; gcoef[32 + tid] = gbase[32 + tid] * sc; gcoef[64 + tid] = gbase[64 + tid] * sc;
+        }
+        cur_n = n;
+        __syncthreads();
+      }
+      store_tile(tile);
+      __syncthreads();
+      if (tile + 1 < t_end) load_tile(tile + 1);
+      mfma_tile();
+      __syncthreads();
+    }
+  } else {
   int cur_n = -1;
   for (int tile = t_begin; tile < t_end; ++tile) {
     int b = tile;
@@ -139,20 +292,9 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
       Ys[m * YS + t] = ok ? o : 0.f;
     }
     __syncthreads();
-#pragma unroll 1
-    for (int s0 = 0; s0 < 32; s0 += 8) {   // groups of 8 k-steps keep the operand prefetch inside the register budget
-      const int wx0 = s0 % TW, hy0 = (s0 / TW) % TH, dz0 = s0 / (TW * TH);
-      const float* xg = xl + (dz0 * HS + hy0) * RS + wx0;
-      const float* yg = yl + s0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int p0 = (i / TW) * RS + (i % TW);   // a group never crosses a depth slice (TH*TW >= 16)
-        const float av = yg[i];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xg[p0 + kw], acc[kw], 0, 0, 0);
-      }
-    }
+    mfma_tile();
     __syncthreads();
+  }
   }
   // ---- partial result: slab[split][tap][m][c] ----
   float* out = a.slab + (long)split * a.slab_stride;
@@ -213,6 +355,108 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
   const float* bl = Bs + (wave * 32 + l31) * S + 32 * half;
   const bool vec = (V & 3) == 0 && ((((uintptr_t)a.x | (uintptr_t)a.g0 | (uintptr_t)a.g1) & 15) == 0);
 
+  // ---- MFMA over one staged chunk of 64 voxels: 32 k-steps x 4 output-channel tiles, operand reads one step ahead ----
+  auto mfma_chunk = [&]() {
+    auto rd = [&](int s, float (&av)[4], float& bv) {
+      bv = bl[s];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) av[t] = al[t * 32 * S + s];
+    };
+    auto mm = [&](const float (&av)[4], float bv) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+    };
+    float a0[4], a1[4], b0, b1;
+    rd(0, a0, b0);
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+      rd(s + 1, a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      mm(a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (s + 2 < 32) rd(s + 2, a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      mm(a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+
+  if (vec) {
+    // ===== fast path: unconditional 16-byte loads of chunk k+1 in flight during the MFMA loop of chunk k =====
+    constexpr int A_ITEMS = 128 * (VK / 4), B_ITEMS = CB * (VK / 4);
+    constexpr int A_IT = (A_ITEMS + NTHREADS - 1) / NTHREADS, B_IT = (B_ITEMS + NTHREADS - 1) / NTHREADS;
+    f32x4 ga[A_IT], gb[A_IT], xb[B_IT];
+    unsigned oka = 0, okb = 0;
+    auto load_chunk = [&](int ch) {
+      const int n = ch / chunks_per_n, v0 = (ch % chunks_per_n) * VK;
+      const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
+      const float* g0n = a.g0 + (long)n * a.g0_ns + (long)(a.g0_coff + m0) * V;
+      const float* g1n = a.g1 + (long)n * a.g1_ns + (long)(a.g1_coff + m0) * V;
+      oka = okb = 0;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        const int q = it % (VK / 4), m = it / (VK / 4);
+        const int v = v0 + 4 * q;
+        const bool ok = (it < A_ITEMS) && m0 + m < a.M && v < V;
+        const long go = ok ? (long)m * V + v : 0;
+        oka |= (ok ? 1u : 0u) << i;
+        ga[i] = *reinterpret_cast<const f32x4*>(g0n + go);
+        gb[i] = *reinterpret_cast<const f32x4*>(g1n + go);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        const int q = it % (VK / 4), c = it / (VK / 4);
+        const int v = v0 + 4 * q;
+        const bool ok = (it < B_ITEMS) && c0 + c < a.Cin && v < V;
+        okb |= (ok ? 1u : 0u) << i;
+        xb[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? (long)c * V + v : 0));
+      }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < A_ITEMS) {
+          const int q = it % (VK / 4), m = it / (VK / 4);
+          const bool ok = (oka >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            As[m * S + 4 * q + e] = ok ? fmaf(gcoef[m], ga[i][e], fmaf(gcoef[128 + m], gb[i][e], gcoef[256 + m])) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int it = tid + i * NTHREADS;
+        if (it < B_ITEMS) {
+          const int q = it % (VK / 4), c = it / (VK / 4);
+          const bool ok = (okb >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            Bs[c * S + 4 * q + e] = ok ? ((PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[c], xb[i][e], xcoef[CB + c]), 0.f) : xb[i][e]) : 0.f;
+        }
+      }
+    };
+    int cur_n = -1;
+    if (k_begin < k_end) load_chunk(k_begin);
+    for (int ch = k_begin; ch < k_end; ++ch) {
+      const int n = ch / chunks_per_n;
+      if (n != cur_n) {
+        for (int m = tid; m < 128; m += NTHREADS) {
+          const float sc = drop_scale(a.drop, n, m0 + m);
+          gcoef[m] = gbase[m] * sc; gcoef[128 + m] = gbase[128 + m] * sc; gcoef[256 + m] = gbase[256 + m] * sc;
+        }
+        cur_n = n;
+        __syncthreads();
+      }
+      store_chunk();
+      __syncthreads();
+      if (ch + 1 < k_end) load_chunk(ch + 1);
+      mfma_chunk();
+      __syncthreads();
+    }
+  } else {
   int cur_n = -1;
   for (int ch = k_begin; ch < k_end; ++ch) {
     const int n = ch / chunks_per_n;
@@ -272,16 +516,9 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
       }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int s0 = 0; s0 < 32; s0 += 8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float bv = bl[s0 + i];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(al[t * 32 * S + s0 + i], bv, acc[t], 0, 0, 0);
-      }
-    }
+    mfma_chunk();
     __syncthreads();
+  }
   }
   float* out = a.slab + (long)split * a.slab_stride;
   const int c = c0 + wave * 32 + l31;
