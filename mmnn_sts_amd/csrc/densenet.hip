@@ -102,6 +102,7 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
     }
   }
   p.o_dz2 = cv.take(dz2);
+  p.o_dz2b = cv.take(dz2);
   p.o_dap = cv.take(dap ? dap : 256);
   p.o_dz0 = cv.take((size_t)N * cfg.init_features * V0 * F);
   // forward statistics (fp64, zeroed at the start of every training forward)
@@ -180,6 +181,10 @@ void plan_free(Plan& p) {
   p.host_jobs = nullptr;
   for (hipEvent_t e : p.timer_ev) (void)hipEventDestroy(e);
   p.timer_ev.clear();
+  for (hipEvent_t e : p.sync_ev) (void)hipEventDestroy(e);
+  p.sync_ev.clear();
+  if (p.side) (void)hipStreamDestroy(p.side);
+  p.side = nullptr;
 }
 
 static StatPtr statptr(char* ws, size_t o, int C, int off) {
@@ -428,6 +433,35 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   float* run = p.tab_run;
   int rc;
   MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
+  // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
+  // kernels only consume its products, so they run beside it on `side`, ordered by events.  Matters for the late dense blocks
+  // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
+  if (!p.side && !p.side_tried) {
+    p.side_tried = true;
+    if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
+  }
+  hipStream_t side = p.side ? p.side : stream;
+  const bool two = p.side != nullptr;
+  p.sync_used = 0;
+  auto next_event = [&]() -> hipEvent_t {
+    if (p.sync_used == p.sync_ev.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      p.sync_ev.push_back(e);
+    }
+    return p.sync_ev[p.sync_used++];
+  };
+  // `to` waits for everything enqueued on `from` so far
+  auto order = [&](hipStream_t from, hipStream_t to) -> int {
+    if (!two) return 0;
+    hipEvent_t e = next_event();
+    MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
+    MMNN_HIP(hipEventRecord(e, from));
+    MMNN_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
+  };
+  hipEvent_t dz_free[2] = {nullptr, nullptr};   // side stream finished reading dz2 buffer i
+  int dzbuf = 0;
   auto sptr = [&](int b, int off) { return statptr(ws, p.o_s_x[b], p.ctot_b[b], off); };
   auto concat_grad = [&](int b, int off) {   // BN-backward of concat channels [off, ...) of block b (gammas folded into G)
     BnBwd g;
@@ -475,7 +509,10 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       a.gr_in = concat_grad(b, lo.cin);
       a.drop_in = drop;
       a.w = fptr(ws, p.o_pk_c2b[b][l]); a.w_ld = p.mid;
-      a.out = fptr(ws, p.o_dz2); a.out_ns = tns; a.out_coff = 0;
+      float* dz2 = fptr(ws, dzbuf ? p.o_dz2b : p.o_dz2);
+      if ((rc = order(stream, side))) return rc;            // G slice of this layer is complete: side may start conv2 wgrad
+      if (two && dz_free[dzbuf]) MMNN_HIP(hipStreamWaitEvent(stream, dz_free[dzbuf], 0));   // buffer reuse
+      a.out = dz2; a.out_ns = tns; a.out_coff = 0;
       a.ex = fptr(ws, p.o_t1[b][l]); a.ex_ns = tns; a.ex_coff = 0;
       a.ebn = bn2;
       a.dbeta = dg2.sum; a.dgamma = dg2.sq;
@@ -492,8 +529,9 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
       w2.bn = bn2;
       w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
-      { ScopedTimer t(p, T_CONV2_WGRAD, b, stream); rc = launch_wgrad(w2, 27, PRO_BNRELU, stream); }
+      { ScopedTimer t(p, T_CONV2_WGRAD, b, side); rc = launch_wgrad(w2, 27, PRO_BNRELU, side); }
       if (rc) return rc;
+      if ((rc = order(stream, side))) return rc;            // dZ2 + dgamma2/dbeta2 ready: side may run conv1 wgrad
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
@@ -506,7 +544,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       memset(&d, 0, sizeof(d));
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
       d.Cin = p.mid; d.M = lo.cin;
-      d.in0 = fptr(ws, p.o_dz2); d.in0_ns = tns; d.in0_coff = 0;
+      d.in0 = dz2; d.in0_ns = tns; d.in0_coff = 0;
       d.in1 = fptr(ws, p.o_t1[b][l]); d.in1_ns = tns; d.in1_coff = 0;
       d.gr_in = g1;
       d.w = params + lo.c1; d.w_ld = lo.cin;
@@ -528,8 +566,15 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
       w1.bn = bn1;
       w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
-      { ScopedTimer t(p, T_CONV1_WGRAD, b, stream); rc = launch_wgrad(w1, 1, PRO_BNRELU, stream); }
+      { ScopedTimer t(p, T_CONV1_WGRAD, b, side); rc = launch_wgrad(w1, 1, PRO_BNRELU, side); }
       if (rc) return rc;
+      if (two) {
+        hipEvent_t e = next_event();
+        MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
+        MMNN_HIP(hipEventRecord(e, side));
+        dz_free[dzbuf] = e;
+        dzbuf ^= 1;
+      }
     }
     if (b > 0) {
       const int pb = b - 1;
@@ -595,6 +640,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       if (rc) return rc;
     }
   }
+  if ((rc = order(side, stream))) return rc;                // join: every weight-gradient slab is written
   return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), p.n_grad_jobs, p.max_grad, grad_params, accumulate, stream);
 }
 

@@ -39,7 +39,7 @@ struct Plan {
   int n_bn;
   // workspace (byte offsets)
   size_t ws_bytes;
-  size_t o_conv0, o_idx, o_x[MAX_BLOCKS], o_g[MAX_BLOCKS], o_ap[MAX_BLOCKS], o_dz2, o_dap, o_dz0;
+  size_t o_conv0, o_idx, o_x[MAX_BLOCKS], o_g[MAX_BLOCKS], o_ap[MAX_BLOCKS], o_dz2, o_dz2b, o_dap, o_dz0;
   std::vector<std::vector<size_t>> o_t1;
   // fp64 statistics: one zero-filled region for forward sums, one for backward sums
   size_t o_fstat, fstat_bytes, o_bstat, bstat_bytes;
@@ -64,6 +64,9 @@ struct Plan {
   // cached identity of the buffers the tables were built for
   const float* tab_params = nullptr; float* tab_run = nullptr; char* tab_ws = nullptr;
   int n_run_jobs = 0, n_pack_jobs = 0, n_grad_jobs = 0; long max_pack = 0, max_grad = 0;
+  // backward runs the weight-gradient kernels on a second stream beside the data-gradient chain (host objects only)
+  hipStream_t side = nullptr; bool side_tried = false;
+  std::vector<hipEvent_t> sync_ev; size_t sync_used = 0;
   // optional live timing of one kernel class with HIP events (bench.py roofline leg)
   int timer_kind = 0, timer_block = -1;            // kind: see TimerKind; block < 0: every block
   std::vector<hipEvent_t> timer_ev;                // start/stop pairs recorded since the last read

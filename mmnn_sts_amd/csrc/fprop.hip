@@ -43,7 +43,7 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
     const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
     if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
     if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
-    return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 32, 1, 1, 32>(a, s);
+    return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 128, 1, 1, 32>(a, s);   // few voxels: deep K chunks (the K loop is latency-bound)
   }
   if (a.M <= 32) {
     if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32>(a, s);
