@@ -138,7 +138,8 @@ def main():
     from mmnn_sts_amd.optim import FusedSGD
     from mmnn_sts_amd.utils.utils import surv_criterion
 
-    rank, world, local = D.init_from_env("nccl")
+    rank, world, local = D.init_from_env(os.environ.get("MMNN_DIST_BACKEND", "nccl"))   # "nccl" = RCCL; gloo only for rehearsals
+    local = local % max(1, torch.cuda.device_count())
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)

@@ -216,9 +216,14 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     constexpr int XV_IT = (XV_ITEMS + NTHREADS - 1) / NTHREADS, XH_IT = (XH_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr bool GR = (PRO == PRO_GRAD);
-    f32x4 xv0[XV_IT], xv1[GR ? XV_IT : 1], wr[W_IT];
-    float xh0[XH_IT > 0 ? XH_IT : 1], xh1[(GR && XH_IT > 0) ? XH_IT : 1];
-    unsigned okv = 0, okh = 0;
+    // small tiles (one accumulator per wave) are latency-bound in this loop: keep TWO chunks of loads in flight
+    constexpr int PF = (MT * NT == 1) ? 2 : 1;
+    struct Stage {
+      f32x4 xv0[XV_IT], xv1[GR ? XV_IT : 1], wr[W_IT];
+      float xh0[XH_IT > 0 ? XH_IT : 1], xh1[(GR && XH_IT > 0) ? XH_IT : 1];
+      unsigned okv, okh;
+    };
+    Stage stA, stB;
 
     // row r of the staged box -> (local channel, offset of the row start in LDS, global row offset, row validity)
     auto row_info = [&](int r, int c0, int& cl, int& lrow, long& gro, bool& rowok) {
@@ -240,8 +245,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     // NOTE: every load below is UNCONDITIONAL (out-of-range items read element 0 of their tensor and are zeroed when
     // they are written to LDS).  A load under a divergent `if` makes hipcc branch around it and wait vmcnt(0) at the join,
     // which serialises the whole batch (one memory round trip per item instead of one per chunk).
-    auto load_chunk = [&](int c0) {
-      okv = 0; okh = 0;
+    auto load_chunk = [&](int c0, Stage& st) {
+      unsigned okv = 0, okh = 0;
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
         const int it = tid + i * NTHREADS;
@@ -251,8 +256,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
         const bool ok = (it < XV_ITEMS) && rowok && col < ((TAPS == 27) ? a.W : V);
         const long off = ok ? gro + col : 0;
         okv |= (ok ? 1u : 0u) << i;
-        xv0[i] = *reinterpret_cast<const f32x4*>(in0n + off);
-        if (GR) xv1[i] = *reinterpret_cast<const f32x4*>(in1n + off);
+        st.xv0[i] = *reinterpret_cast<const f32x4*>(in0n + off);
+        if (GR) st.xv1[i] = *reinterpret_cast<const f32x4*>(in1n + off);
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
@@ -263,8 +268,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
         const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
         const long off = ok ? gro + w : 0;
         okh |= (ok ? 1u : 0u) << i;
-        xh0[i] = in0n[off];
-        if (GR) xh1[i] = in1n[off];
+        st.xh0[i] = in0n[off];
+        if (GR) st.xh1[i] = in1n[off];
       }
       const long kbase = (long)c0 * TAPS, klim = (long)a.Cin * TAPS;
 #pragma unroll
@@ -273,11 +278,13 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
         const int q = it % (M_B / 4), kr = it / (M_B / 4);
         const bool ok = (it < W_ITEMS) && (kbase + kr < klim) && (m0 + 4 * q < a.M);
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (ok ? (kbase + kr) * a.w_ld + m0 + 4 * q : 0));
-        wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        st.wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      st.okv = okv; st.okh = okh;
     };
 
-    auto store_chunk = [&](int c0) {
+    auto store_chunk = [&](int c0, const Stage& st) {
+      const unsigned okv = st.okv, okh = st.okh;
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
         const int it = tid + i * NTHREADS;
@@ -286,7 +293,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
           row_info(it / VPR, c0, cl, lrow, gro, rowok);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c0 + cl, xv0[i][e], GR ? xv1[i][e] : 0.f);
+          for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c0 + cl, st.xv0[i][e], GR ? st.xv1[i][e] : 0.f);
           if (!((okv >> i) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(Xs + lrow + ((TAPS == 27) ? 4 : 0) + 4 * (it % VPR)) = o;
         }
@@ -297,24 +304,43 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
         if (it < XH_ITEMS) {
           int cl, lrow; long gro; bool rowok;
           row_info(it >> 1, c0, cl, lrow, gro, rowok);
-          const float o = pro_apply<PRO>(coef, cpad, c0 + cl, xh0[i], GR ? xh1[i] : 0.f);
+          const float o = pro_apply<PRO>(coef, cpad, c0 + cl, st.xh0[i], GR ? st.xh1[i] : 0.f);
           Xs[lrow + ((it & 1) ? TW + 4 : 3)] = ((okh >> i) & 1u) ? o : 0.f;
         }
       }
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
         const int it = tid + i * NTHREADS;
-        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + 4 * it) = wr[i];
+        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + 4 * it) = st.wr[i];
       }
     };
 
-    load_chunk(0);
-    for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-      store_chunk(c0);
-      __syncthreads();
-      if (c0 + KC < a.Cin) load_chunk(c0 + KC);
-      mfma_chunk();
-      __syncthreads();
+    if (PF == 1) {
+      load_chunk(0, stA);
+      for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+        store_chunk(c0, stA);
+        __syncthreads();
+        if (c0 + KC < a.Cin) load_chunk(c0 + KC, stA);
+        mfma_chunk();
+        __syncthreads();
+      }
+    } else {
+      load_chunk(0, stA);
+      if (KC < a.Cin) load_chunk(KC, stB);
+      for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
+        store_chunk(c0, stA);
+        __syncthreads();
+        if (c0 + 2 * KC < a.Cin) load_chunk(c0 + 2 * KC, stA);
+        mfma_chunk();
+        __syncthreads();
+        if (c0 + KC < a.Cin) {
+          store_chunk(c0 + KC, stB);
+          __syncthreads();
+          if (c0 + 3 * KC < a.Cin) load_chunk(c0 + 3 * KC, stB);
+          mfma_chunk();
+          __syncthreads();
+        }
+      }
     }
   } else {
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
