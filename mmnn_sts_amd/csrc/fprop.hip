@@ -6,10 +6,10 @@
 
 namespace mmnn {
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
 static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
-  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
-  auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
+  auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
   size_t smem = C::smem_bytes(a.Cin);
   MMNN_REQUIRE(smem <= 160 * 1024, "fprop: %zu bytes of LDS needed (Cin=%d) exceeds 160 KiB", smem, a.Cin);
   {
@@ -41,18 +41,18 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
   if (TAPS == 1) {
     const long blocks_a = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
     const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
-    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
+    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128, true>(a, s);
     if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
     return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 128, 1, 1, 32>(a, s);   // few voxels: deep K chunks (the K loop is latency-bound)
   }
   if (a.M <= 32) {
-    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32>(a, s);
+    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>(a, s);
     if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 2, 4, 1, 1, 16, 1, 4, 16>(a, s);
     if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
   }
-  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);
-  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
+  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32, true>(a, s);
+  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16, true>(a, s);
   if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);
   return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 2, 4, 4>(a, s);
 }

@@ -43,10 +43,13 @@ int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t str
 
 #if defined(__HIPCC__)
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
 struct FpropCfg {
   static constexpr int NWAVES = WM * WN * KS;          // KS wave groups split the channel (reduction) axis of every chunk
-  static constexpr int NTHREADS = NWAVES * 64;
+  // SPEC: wave specialisation -- a second set of NWAVES "loader" waves stages chunk k+1 into the other LDS buffer while
+  // the compute waves run the MFMAs of chunk k (one loader + one compute wave per SIMD: VALU/LDS-write beside the matrix pipe)
+  static constexpr int NCOMPUTE = NWAVES * 64;
+  static constexpr int NTHREADS = NCOMPUTE * (SPEC ? 2 : 1);
   static constexpr int M_B = WM * MT * 32;
   static constexpr int V_B = WN * NT * 32;
   static constexpr int RS = (TAPS == 27) ? TW + 8 : TW;
@@ -59,7 +62,7 @@ struct FpropCfg {
   static_assert(KC % 2 == 0 && (KC / 2) % KS == 0, "channel-pair count of a chunk must be a multiple of the K-split");
   static constexpr int STAGE = KC * XS + KC * TAPS * M_B;                       // floats: activations + weights of a chunk
   static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
-  static constexpr int BUF = STAGE > REDN ? STAGE : REDN;
+  static constexpr int BUF = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
   static size_t smem_bytes(int Cin) {
     int cpad = ((Cin + KC - 1) / KC) * KC;
     size_t ncoef = ((size_t)NCOEF * cpad + 3) & ~(size_t)3;   // keep the staging buffers 16-byte aligned
@@ -74,12 +77,16 @@ __device__ __forceinline__ float pro_apply(const float* coef, int cpad, int c, f
   return x0;
 }
 
-template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW>
-__global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs a) {
-  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW>;
+template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
+__global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel(const FpropArgs a) {
+  using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
+  constexpr int NL = C::NCOMPUTE;                         // threads that take part in staging (fast path)
   constexpr int NTHREADS = C::NTHREADS, M_B = C::M_B, V_B = C::V_B, RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool loader = SPEC && tid >= NL;                 // wave-uniform role
+  const int ltid = loader ? tid - NL : tid;              // index within the role's thread set
+  const int wave = ltid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int kg = wave / (WM * WN);                      // K-split group of this wave
   const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
@@ -88,7 +95,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
 
   float* coef = smem;
   float* Xs = coef + ((C::NCOEF * cpad + 3) & ~3);
-  float* Ws = Xs + KC * XS;
+  float* Ws = Xs + KC * XS;                              // buffer 0; buffer 1 (SPEC) follows at + C::STAGE
   float* ecoef = Xs + C::BUF;
 
   // ---- which tile ----
@@ -171,9 +178,9 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
 
   // ---- MFMA over one staged chunk.  The operand reads of step s+1 are issued before the MFMAs of step s (two register
   // sets), so that the LDS latency hides behind the matrix pipe even with a single wave per SIMD. ----
-  auto mfma_chunk = [&]() {
-    const float* xb = Xs + (2 * kg + half) * XS;
-    const float* wb = Ws + (2 * kg + half) * TAPS * M_B + wm * MT * 32 + l31;
+  auto mfma_chunk = [&](int boff = 0) {
+    const float* xb = Xs + boff + (2 * kg + half) * XS;
+    const float* wb = Ws + boff + (2 * kg + half) * TAPS * M_B + wm * MT * 32 + l31;
     constexpr int PAIR = 2 * KS;                 // channel distance between consecutive pairs of one wave group
     constexpr int NSTEP = (KC / 2 / KS) * TAPS;
     auto rd = [&](int st, float (&av)[MT], float (&bv)[NT]) {
@@ -205,7 +212,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     }
   };
 
-  if (vecx && vecw) {
+  if (vecx && vecw && (long)KC * V < (1l << 30)) {
     // ===== fast path: 16-byte staging through registers, software-pipelined.  The global loads of chunk k+1 are issued
     // (all at once) before the MFMA loop of chunk k and only waited for when they are written to LDS afterwards. =====
     constexpr int ROWS = (TAPS == 27) ? KC * DS * HS : KC;                   // staged rows (channel x halo row)
@@ -213,8 +220,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     constexpr int XV_ITEMS = ROWS * VPR;
     constexpr int XH_ITEMS = (TAPS == 27) ? ROWS * 2 : 0;                     // halo columns: one float each
     constexpr int W_ITEMS = KC * TAPS * (M_B / 4);
-    constexpr int XV_IT = (XV_ITEMS + NTHREADS - 1) / NTHREADS, XH_IT = (XH_ITEMS + NTHREADS - 1) / NTHREADS;
-    constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int XV_IT = (XV_ITEMS + NL - 1) / NL, XH_IT = (XH_ITEMS + NL - 1) / NL;
+    constexpr int W_IT = (W_ITEMS + NL - 1) / NL;
     constexpr bool GR = (PRO == PRO_GRAD);
     // small tiles (one accumulator per wave) are latency-bound in this loop: keep TWO chunks of loads in flight
     constexpr int PF = (MT * NT == 1) ? 2 : 1;
@@ -225,97 +232,134 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     };
     Stage stA, stB;
 
-    // row r of the staged box -> (local channel, offset of the row start in LDS, global row offset, row validity)
-    auto row_info = [&](int r, int c0, int& cl, int& lrow, long& gro, bool& rowok) {
-      if (TAPS == 27) {
-        const int hy = r % HS, dz = (r / HS) % DS;
-        cl = r / (HS * DS);
-        const int d = d0 + dz - 1, h = h0 + hy - 1;
-        rowok = (c0 + cl < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
-        gro = (long)(c0 + cl) * V + ((long)d * a.H + h) * a.W;
-        lrow = cl * XS + (dz * HS + hy) * RS;
-      } else {
-        cl = r;
-        rowok = c0 + cl < a.Cin;
-        gro = (long)(c0 + cl) * V;
-        lrow = cl * XS;
+    // Per-item descriptors, computed ONCE: element offset relative to the chunk's first channel (-1: never valid), LDS
+    // destination and local channel.  The per-chunk staging code is then one add + one select per item -- with one wave per
+    // SIMD every integer instruction spent here is a cycle the matrix pipe idles.
+    int xv_off[XV_IT], xv_dst[XV_IT], xv_cl[XV_IT];
+    int xh_off[XH_IT > 0 ? XH_IT : 1], xh_dst[XH_IT > 0 ? XH_IT : 1], xh_cl[XH_IT > 0 ? XH_IT : 1];
+    int w_off[W_IT], w_cl[W_IT];
+    {
+      auto row_info = [&](int r, int& cl, int& lrow, long& gro, bool& rowok) {
+        if (TAPS == 27) {
+          const int hy = r % HS, dz = (r / HS) % DS;
+          cl = r / (HS * DS);
+          const int d = d0 + dz - 1, h = h0 + hy - 1;
+          rowok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
+          gro = (long)cl * V + ((long)d * a.H + h) * a.W;
+          lrow = cl * XS + (dz * HS + hy) * RS;
+        } else {
+          cl = r;
+          rowok = true;
+          gro = (long)cl * V;
+          lrow = cl * XS;
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) {
+        const int it = ltid + i * NL;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it / VPR, cl, lrow, gro, rowok);
+        const int col = ((TAPS == 27) ? w0 : v0_) + 4 * (it % VPR);
+        const bool ok = (it < XV_ITEMS) && rowok && col < ((TAPS == 27) ? a.W : V);
+        xv_off[i] = ok ? (int)(gro + col) : -1;
+        xv_dst[i] = lrow + ((TAPS == 27) ? 4 : 0) + 4 * (it % VPR);
+        xv_cl[i] = cl;
       }
-    };
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) {
+        const int it = ltid + i * NL;
+        int cl, lrow; long gro; bool rowok;
+        row_info(it >> 1, cl, lrow, gro, rowok);
+        const int w = (it & 1) ? w0 + TW : w0 - 1;
+        const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
+        xh_off[i] = ok ? (int)(gro + w) : -1;
+        xh_dst[i] = lrow + ((it & 1) ? TW + 4 : 3);
+        xh_cl[i] = cl;
+      }
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int it = ltid + i * NL;
+        const int q = it % (M_B / 4), kr = it / (M_B / 4);
+        const bool ok = (it < W_ITEMS) && (m0 + 4 * q < a.M);
+        w_off[i] = ok ? kr * a.w_ld + m0 + 4 * q : -1;
+        w_cl[i] = kr / TAPS;
+      }
+    }
 
     // NOTE: every load below is UNCONDITIONAL (out-of-range items read element 0 of their tensor and are zeroed when
     // they are written to LDS).  A load under a divergent `if` makes hipcc branch around it and wait vmcnt(0) at the join,
     // which serialises the whole batch (one memory round trip per item instead of one per chunk).
     auto load_chunk = [&](int c0, Stage& st) {
       unsigned okv = 0, okh = 0;
+      const float* b0 = in0n + (long)c0 * V;
+      const float* b1 = GR ? in1n + (long)c0 * V : nullptr;
+      const int crem = a.Cin - c0;                    // channels left: items of local channel >= crem are padding
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        int cl, lrow; long gro; bool rowok;
-        row_info(it / VPR, c0, cl, lrow, gro, rowok);
-        const int col = ((TAPS == 27) ? w0 : v0_) + 4 * (it % VPR);
-        const bool ok = (it < XV_ITEMS) && rowok && col < ((TAPS == 27) ? a.W : V);
-        const long off = ok ? gro + col : 0;
+        const bool ok = xv_off[i] >= 0 && xv_cl[i] < crem;
+        const int off = ok ? xv_off[i] : 0;
         okv |= (ok ? 1u : 0u) << i;
-        st.xv0[i] = *reinterpret_cast<const f32x4*>(in0n + off);
-        if (GR) st.xv1[i] = *reinterpret_cast<const f32x4*>(in1n + off);
+        st.xv0[i] = *reinterpret_cast<const f32x4*>(ok ? b0 + off : in0n);
+        if (GR) st.xv1[i] = *reinterpret_cast<const f32x4*>(ok ? b1 + off : in1n);
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        int cl, lrow; long gro; bool rowok;
-        row_info(it >> 1, c0, cl, lrow, gro, rowok);
-        const int w = (it & 1) ? w0 + TW : w0 - 1;
-        const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
-        const long off = ok ? gro + w : 0;
+        const bool ok = xh_off[i] >= 0 && xh_cl[i] < crem;
+        const int off = ok ? xh_off[i] : 0;
         okh |= (ok ? 1u : 0u) << i;
-        st.xh0[i] = in0n[off];
-        if (GR) st.xh1[i] = in1n[off];
+        st.xh0[i] = ok ? b0[off] : in0n[0];
+        if (GR) st.xh1[i] = ok ? b1[off] : in1n[0];
       }
-      const long kbase = (long)c0 * TAPS, klim = (long)a.Cin * TAPS;
+      const float* bw = a.w + (long)c0 * TAPS * a.w_ld;
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        const int q = it % (M_B / 4), kr = it / (M_B / 4);
-        const bool ok = (it < W_ITEMS) && (kbase + kr < klim) && (m0 + 4 * q < a.M);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (ok ? (kbase + kr) * a.w_ld + m0 + 4 * q : 0));
+        const bool ok = w_off[i] >= 0 && w_cl[i] < crem;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? bw + w_off[i] : a.w);
         st.wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       st.okv = okv; st.okh = okh;
     };
 
-    auto store_chunk = [&](int c0, const Stage& st) {
+    auto store_chunk = [&](int c0, const Stage& st, int boff = 0) {
       const unsigned okv = st.okv, okh = st.okh;
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        if (it < XV_ITEMS) {
-          int cl, lrow; long gro; bool rowok;
-          row_info(it / VPR, c0, cl, lrow, gro, rowok);
+        if (ltid + i * NL < XV_ITEMS) {
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c0 + cl, st.xv0[i][e], GR ? st.xv1[i][e] : 0.f);
+          for (int e = 0; e < 4; ++e) o[e] = pro_apply<PRO>(coef, cpad, c0 + xv_cl[i], st.xv0[i][e], GR ? st.xv1[i][e] : 0.f);
           if (!((okv >> i) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(Xs + lrow + ((TAPS == 27) ? 4 : 0) + 4 * (it % VPR)) = o;
+          *reinterpret_cast<f32x4*>(Xs + boff + xv_dst[i]) = o;
         }
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        if (it < XH_ITEMS) {
-          int cl, lrow; long gro; bool rowok;
-          row_info(it >> 1, c0, cl, lrow, gro, rowok);
-          const float o = pro_apply<PRO>(coef, cpad, c0 + cl, st.xh0[i], GR ? st.xh1[i] : 0.f);
-          Xs[lrow + ((it & 1) ? TW + 4 : 3)] = ((okh >> i) & 1u) ? o : 0.f;
+        if (ltid + i * NL < XH_ITEMS) {
+          const float o = pro_apply<PRO>(coef, cpad, c0 + xh_cl[i], st.xh0[i], GR ? st.xh1[i] : 0.f);
+          Xs[boff + xh_dst[i]] = ((okh >> i) & 1u) ? o : 0.f;
         }
       }
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + 4 * it) = st.wr[i];
+        const int it = ltid + i * NL;
+        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = st.wr[i];
       }
     };
 
-    if (PF == 1) {
+    if (SPEC) {
+      // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
+      if (loader) { load_chunk(0, stA); store_chunk(0, stA, 0); }
+      __syncthreads();
+      int k = 0;
+      for (int c0 = 0; c0 < a.Cin; c0 += KC, ++k) {
+        if (loader) {
+          if (c0 + KC < a.Cin) { load_chunk(c0 + KC, stA); store_chunk(c0 + KC, stA, ((k + 1) & 1) * C::STAGE); }
+        } else {
+          mfma_chunk((k & 1) * C::STAGE);
+        }
+        __syncthreads();
+      }
+    } else if (PF == 1) {
       load_chunk(0, stA);
       for (int c0 = 0; c0 < a.Cin; c0 += KC) {
         store_chunk(c0, stA);
@@ -467,7 +511,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
       }
     }
     __syncthreads();
-    mfma_chunk();
+    if (!loader) mfma_chunk();
     __syncthreads();
   }
   }
@@ -476,7 +520,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
   if (KS > 1) {
     float* rbuf = Xs;   // staging buffers are free after the last barrier
     const int slot = (wm * WN + wn) * MT * NT;
-    if (kg > 0) {
+    if (kg > 0 && !loader) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -485,7 +529,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
           for (int r = 0; r < 16; ++r) rbuf[(((kg - 1) * WM * WN * MT * NT + slot + i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
     }
     __syncthreads();
-    if (kg == 0) {
+    if (kg == 0 && !loader) {
 #pragma unroll
       for (int g = 1; g < KS; ++g)
 #pragma unroll
@@ -520,7 +564,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) fprop_kernel(const FpropArgs 
     }
   }
 
-  if (kg == 0) {
+  if (kg == 0 && !loader) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float s0[16], s1[16];
