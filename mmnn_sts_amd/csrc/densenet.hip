@@ -1,6 +1,7 @@
 // Launch plan of the DenseNet backbone forward / backward (see densenet.hpp).
 #include "densenet.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -438,7 +439,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
   if (!p.side && !p.side_tried) {
     p.side_tried = true;
-    if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
+    const char* off = getenv("MMNN_SINGLE_STREAM");   // debugging / profiling aid: serialise the backward on one stream
+    if ((off && off[0] == '1') || hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
   }
   hipStream_t side = p.side ? p.side : stream;
   const bool two = p.side != nullptr;

@@ -41,7 +41,7 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
   if (TAPS == 1) {
     const long blocks_a = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
     const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
-    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128, true>(a, s);
+    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
     if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
     return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 128, 1, 1, 32>(a, s);   // few voxels: deep K chunks (the K loop is latency-bound)
   }
@@ -51,8 +51,8 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
     if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
   }
-  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32, true>(a, s);
-  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16, true>(a, s);
+  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);   // 2 blocks/CU overlap better than loader waves here
+  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
   if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);
   return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 2, 4, 4>(a, s);
 }

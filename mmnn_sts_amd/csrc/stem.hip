@@ -239,10 +239,21 @@ int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
 // Backward of BN+ReLU+max-pool:  dz[q] = relu'(q) * sum over windows p whose argmax is q of dP[p],
 // dP = BN-backward(G, pooled) on the fly;  also dgamma0 / dbeta0 sums.
 // =====================================================================================================================
+// One block = (n, c, 2 x 8 rows of the conv-output grid, full width).  The <= 2 x 5 x Wo pooled windows that can route a
+// gradient into those rows are staged in LDS once (dP evaluated on the fly + winning tap), then every fine voxel gathers its
+// <= 8 candidates from LDS with branch-free selects: deterministic (no atomics on the tensor), every global load batched.
+constexpr int PB_TD = 2, PB_TH = 8, PB_PD = 2, PB_PH = 5;
+
 __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pb_smem[];
   __shared__ float red[2][4];
   const int c = blockIdx.y, n = blockIdx.z;
   const int Vi = a.Di * a.Hi * a.Wi, Vo = a.Do * a.Ho * a.Wo;
+  const int nh = (a.Hi + PB_TH - 1) / PB_TH;
+  const int d0 = (blockIdx.x / nh) * PB_TD, h0 = (blockIdx.x % nh) * PB_TH;
+  const int pd0 = d0 / 2, ph0 = h0 / 2;
+  float* dP = pb_smem;                                               // [PB_PD][PB_PH][Wo]
+  int* tapw = reinterpret_cast<int*>(pb_smem + PB_PD * PB_PH * a.Wo);   // winning tap of each window (or -1)
   float ca, cb, mu, rs, gp, gq, gr;
   bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
   bn_bwd_coef(a.gr, c, gp, gq, gr);
@@ -250,31 +261,43 @@ __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArg
   const float* gc = a.g + (long)n * a.g_ns + (long)c * Vo;
   const float* pc = a.xp + (long)n * a.xp_ns + (long)c * Vo;
   const unsigned char* ic = a.idx + ((long)n * a.C + c) * Vo;
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int nwin = PB_PD * PB_PH * a.Wo;
+  for (int i = threadIdx.x; i < nwin; i += 256) {
+    const int pw = i % a.Wo, ph = ph0 + (i / a.Wo) % PB_PH, pd = pd0 + i / (a.Wo * PB_PH);
+    const bool ok = pd < a.Do && ph < a.Ho;
+    const long p = ok ? ((long)pd * a.Ho + ph) * a.Wo + pw : 0;
+    const float v = fmaf(gp, gc[p], fmaf(gq, pc[p], gr));
+    const int t = ic[p];
+    dP[i] = ok ? v : 0.f;
+    tapw[i] = ok ? t : -1;
+  }
+  __syncthreads();
   float s0 = 0.f, s1 = 0.f;
-  if (q < Vi) {
-    const int w = q % a.Wi, h = (q / a.Wi) % a.Hi, d = q / (a.Wi * a.Hi);
+  const int nq = PB_TD * PB_TH * a.Wi;
+  for (int i = threadIdx.x; i < nq; i += 256) {
+    const int w = i % a.Wi, h = h0 + (i / a.Wi) % PB_TH, d = d0 + i / (a.Wi * PB_TH);
+    const bool inq = d < a.Di && h < a.Hi;
+    const long q = inq ? ((long)d * a.Hi + h) * a.Wi + w : 0;
     const float x = xc[q];
+    // candidate windows along each axis: even coordinate -> (p = q/2, k = 1); odd -> (p = (q+1)/2, k = 0) and (p = (q-1)/2, k = 2)
+    const int od = d & 1, oh = h & 1, ow = w & 1;
+    const int pdA = (d + 1) / 2 - pd0, kdA = od ? 0 : 1, pdB = (d - 1) / 2 - pd0;   // B valid only for odd coordinates (k = 2)
+    const int phA = (h + 1) / 2 - ph0, khA = oh ? 0 : 1, phB = (h - 1) / 2 - ph0;
+    const int pwA = (w + 1) / 2, kwA = ow ? 0 : 1, pwB = (w - 1) / 2;
     float z = 0.f;
-    if (fmaf(ca, x, cb) > 0.f) {
-      // windows p with 2p-1+k = q, k in {0,1,2}:  q even -> k=1;  q odd -> k=0 (p=(q+1)/2) and k=2 (p=(q-1)/2)
-      int pd[2], kdv[2], nd = 0, ph[2], khv[2], nh = 0, pw[2], kwv[2], nw = 0;
-      if (d & 1) { if ((d + 1) / 2 < a.Do) { pd[nd] = (d + 1) / 2; kdv[nd++] = 0; } pd[nd] = (d - 1) / 2; kdv[nd++] = 2; }
-      else if (d / 2 < a.Do) { pd[nd] = d / 2; kdv[nd++] = 1; }
-      if (h & 1) { if ((h + 1) / 2 < a.Ho) { ph[nh] = (h + 1) / 2; khv[nh++] = 0; } ph[nh] = (h - 1) / 2; khv[nh++] = 2; }
-      else if (h / 2 < a.Ho) { ph[nh] = h / 2; khv[nh++] = 1; }
-      if (w & 1) { if ((w + 1) / 2 < a.Wo) { pw[nw] = (w + 1) / 2; kwv[nw++] = 0; } pw[nw] = (w - 1) / 2; kwv[nw++] = 2; }
-      else if (w / 2 < a.Wo) { pw[nw] = w / 2; kwv[nw++] = 1; }
-      for (int i = 0; i < nd; ++i)
-        for (int j = 0; j < nh; ++j)
-          for (int k = 0; k < nw; ++k) {
-            if (pd[i] >= a.Do || ph[j] >= a.Ho || pw[k] >= a.Wo) continue;
-            const long p = ((long)pd[i] * a.Ho + ph[j]) * a.Wo + pw[k];
-            if (ic[p] == kdv[i] * 9 + khv[j] * 3 + kwv[k]) z += fmaf(gp, gc[p], fmaf(gq, pc[p], gr));
-          }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool bd = e & 4, bh = e & 2, bw = e & 1;
+      const int pd = bd ? pdB : pdA, ph = bh ? phB : phA, pw = bw ? pwB : pwA;
+      const int kd = bd ? 2 : kdA, kh = bh ? 2 : khA, kw = bw ? 2 : kwA;
+      const bool valid = (!bd || od) && (!bh || oh) && (!bw || ow) && pd >= 0 && pd < PB_PD && ph >= 0 && ph < PB_PH && pw < a.Wo;
+      const int li = valid ? (pd * PB_PH + ph) * a.Wo + pw : 0;
+      const bool hit = valid && tapw[li] == kd * 9 + kh * 3 + kw;
+      z += hit ? dP[li] : 0.f;
     }
-    a.dz[((long)n * a.C + c) * Vi + q] = z;
-    s0 = z; s1 = z * (x - mu) * rs;
+    z = (inq && fmaf(ca, x, cb) > 0.f) ? z : 0.f;
+    if (inq) a.dz[((long)n * a.C + c) * Vi + q] = z;
+    s0 += z; s1 += z * (x - mu) * rs;
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   const int wave = threadIdx.x >> 6;
@@ -289,8 +312,10 @@ __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArg
 
 int launch_stem_pool_bwd(const StemPoolBwdArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "stem pool bwd: bad extent");
-  const int Vi = a.Di * a.Hi * a.Wi;
-  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(cdiv(Vi, 256), a.C, a.N), dim3(256), 0, stream, a);
+  const size_t smem = (size_t)PB_PD * PB_PH * a.Wo * 8;
+  MMNN_REQUIRE(smem <= 64 * 1024, "stem pool bwd: row too wide (%d)", a.Wo);
+  const int blocks = cdiv(a.Di, PB_TD) * cdiv(a.Hi, PB_TH);
+  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(blocks, a.C, a.N), dim3(256), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
