@@ -616,6 +616,12 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       q.s_acc = sptr(pb, 0);
       if ((rc = launch_consumer_bwd(q, stream))) return rc;
     } else {
+      // Everything except the stem's own gradients is final now: reduce those slabs on the side stream (HBM-bound) while the
+      // stem backward (MFMA-bound) runs here.  Jobs 0..2 of the table are conv0 / norm0 (see build_tables).
+      if (two) {
+        if ((rc = order(stream, side))) return rc;
+        if ((rc = launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad) + 3, p.n_grad_jobs - 3, p.max_grad, grad_params, accumulate, side))) return rc;
+      }
       const double cnt0 = (double)N * p.D0 * p.H0 * p.W0;
       StemPoolBwdArgs q;
       q.N = N; q.C = c.init_features; q.Di = p.D0; q.Hi = p.H0; q.Wi = p.W0; q.Do = p.Db[0]; q.Ho = p.Hb[0]; q.Wo = p.Wb[0];
@@ -642,8 +648,10 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       if (rc) return rc;
     }
   }
-  if ((rc = order(side, stream))) return rc;                // join: every weight-gradient slab is written
-  return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), p.n_grad_jobs, p.max_grad, grad_params, accumulate, stream);
+  if ((rc = order(side, stream))) return rc;                // join: every weight-gradient slab is written / reduced
+  const long stem_count = (long)c.init_features * c.in_channels * 343;
+  return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), two ? 3 : p.n_grad_jobs, two ? stem_count : p.max_grad,
+                         grad_params, accumulate, stream);
 }
 
 int plan_relu_mask(Plan& p, const float* params, char* ws, int kind, int b, int l, unsigned char* out, hipStream_t stream) {

@@ -361,45 +361,95 @@ __global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradA
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // ---- software pipeline: the (unconditional) global loads of tile t+1 are issued before the MFMA loop of tile t ----
+  constexpr int X_ITEMS = SW_PLANES * SW_ROWS * 37, Y_ITEMS = 64 * 64;
+  constexpr int X_IT = (X_ITEMS + SW_THREADS - 1) / SW_THREADS, Y_IT = (Y_ITEMS + SW_THREADS - 1) / SW_THREADS;
+  float xr[X_IT], y0[Y_IT], y1[Y_IT];
+  unsigned okx = 0, oky = 0;
+  auto origin = [&](int tile, int& n, int& do0, int& ho0, int& wo0) {
     int b = tile;
-    const int wo0 = (b % nw) * SW_TW; b /= nw;
-    const int ho0 = (b % nh) * SW_TH; b /= nh;
-    const int do0 = (b % nd) * SW_TD; b /= nd;
-    const int n = b;
+    wo0 = (b % nw) * SW_TW; b /= nw;
+    ho0 = (b % nh) * SW_TH; b /= nh;
+    do0 = (b % nd) * SW_TD; b /= nd;
+    n = b;
+  };
+  auto load_tile = [&](int tile) {
+    int n, do0, ho0, wo0;
+    origin(tile, n, do0, ho0, wo0);
     const float* xc = a.x + ((long)n * a.Cin + c) * Vi;
-    __syncthreads();
-#pragma unroll 5
-    for (int it = tid; it < SW_PLANES * SW_ROWS * 37; it += SW_THREADS) {
-      const int ci = it % 37;
-      const int r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
+    okx = oky = 0;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int it = tid + i * SW_THREADS;
+      const int ci = it % 37, r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
       const int d = 2 * do0 + pl - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
-      const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-      const float v = xc[ok ? ((long)d * a.H + h) * a.W + w : 0];
-      Xs[pl * SW_PS + r * SW_RS + ci] = ok ? v : 0.f;
+      const bool ok = it < X_ITEMS && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      okx |= (ok ? 1u : 0u) << i;
+      xr[i] = xc[ok ? ((long)d * a.H + h) * a.W + w : 0];
     }
-#pragma unroll 6
-    for (int it = tid; it < 64 * 64; it += SW_THREADS) {
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int it = tid + i * SW_THREADS;
       const int t = it & 63, m = it >> 6;
       const int wx = t % SW_TW, hy = (t / SW_TW) % SW_TH, dz = t / (SW_TW * SW_TH);
       const int d = do0 + dz, h = ho0 + hy, w = wo0 + wx;
-      const bool ok = m < a.M && d < a.Do && h < a.Ho && w < a.Wo;
+      const bool ok = it < Y_ITEMS && m < a.M && d < a.Do && h < a.Ho && w < a.Wo;
       const long g = ok ? ((long)n * a.M + m) * Vo + ((long)d * a.Ho + h) * a.Wo + w : 0;
-      const float o = fmaf(gcoef[m], a.dz[g], fmaf(gcoef[64 + m], a.y[g], gcoef[128 + m]));
-      Ys[m * SW_YS + t] = ok ? o : 0.f;
+      oky |= (ok ? 1u : 0u) << i;
+      y0[i] = a.dz[g];
+      y1[i] = a.y[g];
     }
-    __syncthreads();
-#pragma unroll 1
-    for (int s0 = 0; s0 < 32; s0 += 8) {
-      const float* xg = xl + (2 * (s0 / SW_TW)) * SW_RS + 2 * (s0 % SW_TW);   // s < 32: dz = 0, hy = s/16, wx = s%16
-      const float* yg = yl + s0;
+  };
+  auto store_tile = [&]() {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float bv = xg[2 * i];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yg[i], bv, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yg[32 * SW_YS + i], bv, acc[1], 0, 0, 0);
+    for (int i = 0; i < X_IT; ++i) {
+      const int it = tid + i * SW_THREADS;
+      if (it < X_ITEMS) {
+        const int ci = it % 37, r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
+        Xs[pl * SW_PS + r * SW_RS + ci] = ((okx >> i) & 1u) ? xr[i] : 0.f;
       }
     }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int it = tid + i * SW_THREADS;
+      if (it < Y_ITEMS) {
+        const int t = it & 63, m = it >> 6;
+        Ys[m * SW_YS + t] = ((oky >> i) & 1u) ? fmaf(gcoef[m], y0[i], fmaf(gcoef[64 + m], y1[i], gcoef[128 + m])) : 0.f;
+      }
+    }
+  };
+  auto mfma_tile = [&]() {   // 32 k-steps x 2 output-channel tiles; operand reads one step ahead of the MFMAs
+    auto rd = [&](int s, float (&av)[2], float& bv) {
+      bv = xl[(2 * (s / SW_TW)) * SW_RS + 2 * (s % SW_TW)];      // s < 32: dz = 0, hy = s/16, wx = s%16
+      av[0] = yl[s];
+      av[1] = yl[32 * SW_YS + s];
+    };
+    auto mm = [&](const float (&av)[2], float bv) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, acc[1], 0, 0, 0);
+    };
+    float a0[2], a1[2], b0, b1;
+    rd(0, a0, b0);
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+      rd(s + 1, a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      mm(a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (s + 2 < 32) rd(s + 2, a0, b0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      mm(a1, b1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+  };
+  __syncthreads();                                   // gcoef visible
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    store_tile();
+    __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
+    mfma_tile();
+    __syncthreads();
   }
   float* out = a.slab + (long)split * a.slab_stride + (long)c * a.M * 352;
 #pragma unroll
