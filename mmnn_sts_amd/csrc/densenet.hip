@@ -161,6 +161,10 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
       p.o_sl_tr.push_back(cv.take((size_t)s * p.trans[b].cout * p.trans[b].cin * F));
     }
   }
+  // cross-block K-split scratch: <= 256 blocks x one 32x32 (or 4 x 32x32) partial tile each, + per-tile counters
+  constexpr size_t KZ_PART = (size_t)512 * 4 * 1024 * sizeof(float), KZ_CNT = 4096;
+  p.o_kz_part = cv.take(KZ_PART);
+  p.o_kz_cnt = cv.take(KZ_CNT * sizeof(unsigned));
   // job tables
   int nlayers = 0;
   for (int b = 0; b < nb; ++b) nlayers += cfg.block_layers[b];
@@ -336,6 +340,8 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   build_tables(p, params, run, ws);
   MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
   if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
+  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, 4096 * sizeof(unsigned), stream));
+  kz_part_bytes = (size_t)512 * 4 * 1024 * sizeof(float); kz_cnt_entries = 4096;
   int rc = launch_pack(reinterpret_cast<const PackJob*>(ws + p.o_jobs_pack), p.n_pack_jobs, p.max_pack, stream);
   if (rc) return rc;
 
@@ -366,6 +372,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       const LayerOff& lo = p.layers[b][l];
       FpropArgs a;
       memset(&a, 0, sizeof(a));
+      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
       // conv1: ReLU(BN(concat)) -> T1
       a.Cin = lo.cin; a.M = p.mid;
@@ -380,6 +387,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       // conv2: ReLU(BN(T1)) -> growth new channels of the concat buffer (+ channel dropout)
       FpropArgs e;
       memset(&e, 0, sizeof(e));
+      e.kz_part = fptr(ws, p.o_kz_part); e.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       e.N = N; e.D = p.Db[b]; e.H = p.Hb[b]; e.W = p.Wb[b];
       e.Cin = p.mid; e.M = c.growth;
       e.in0 = fptr(ws, p.o_t1[b][l]); e.in0_ns = (long)p.mid * p.Vb[b]; e.in0_coff = 0;
@@ -402,6 +410,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       if ((rc = launch_bnrelu_avgpool(q, stream))) return rc;
       FpropArgs a;
       memset(&a, 0, sizeof(a));
+      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       a.N = N; a.D = p.Db[b + 1]; a.H = p.Hb[b + 1]; a.W = p.Wb[b + 1];
       a.Cin = t.cin; a.M = t.cout;
       a.in0 = fptr(ws, p.o_ap[b]); a.in0_ns = (long)t.cin * p.Vb[b + 1]; a.in0_coff = 0;
@@ -434,6 +443,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   float* run = p.tab_run;
   int rc;
   MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
+  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, 4096 * sizeof(unsigned), stream));
   // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
   // kernels only consume its products, so they run beside it on `side`, ordered by events.  Matters for the late dense blocks
   // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
@@ -504,6 +514,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // conv2 data gradient -> dZ2 (ReLU mask of norm2 applied) + dgamma2/dbeta2
       FpropArgs a;
       memset(&a, 0, sizeof(a));
+      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
       a.Cin = c.growth; a.M = p.mid;
       a.in0 = fptr(ws, p.o_g[b]); a.in0_ns = xns; a.in0_coff = lo.cin;
@@ -544,6 +555,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // conv1 data gradient -> G[0:cin) += gamma1 * mask * (...), dgamma1/dbeta1, S1/S2
       FpropArgs d;
       memset(&d, 0, sizeof(d));
+      d.kz_part = fptr(ws, p.o_kz_part); d.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
       d.Cin = p.mid; d.M = lo.cin;
       d.in0 = dz2; d.in0_ns = tns; d.in0_coff = 0;
@@ -596,6 +608,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // transition conv data gradient -> gradient wrt the pooled activations
       FpropArgs d;
       memset(&d, 0, sizeof(d));
+      d.kz_part = fptr(ws, p.o_kz_part); d.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
       d.Cin = t.cout; d.M = t.cin;
       d.in0 = w.g0; d.in0_ns = xns; d.in0_coff = 0;

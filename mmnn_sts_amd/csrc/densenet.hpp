@@ -59,6 +59,7 @@ struct Plan {
   std::vector<std::vector<int>> ns_c1, ns_c2;
   std::vector<size_t> o_sl_tr; std::vector<int> ns_tr;
   // device job tables (inside the workspace) + pinned host staging
+  size_t o_kz_part, o_kz_cnt;                       // cross-block K-split scratch (fprop.hpp)
   size_t o_jobs_run, o_jobs_pack, o_jobs_grad;
   void* host_jobs = nullptr; size_t host_jobs_bytes = 0;
   // cached identity of the buffers the tables were built for

@@ -6,8 +6,12 @@
 
 namespace mmnn {
 
+// capacity of the K-split scratch the plan provides (densenet.hip); the split is skipped when it would not fit
+size_t kz_part_bytes = 0, kz_cnt_entries = 0;
+
 template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
 static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
+  constexpr bool KZ_OK = (MT * NT == 1) || (TAPS == 27 && TW <= 16);   // only the small-extent tiles are ever short of blocks
   using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
   auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
   size_t smem = C::smem_bytes(a.Cin);
@@ -26,7 +30,17 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   else tiles = (long)a.N * cdiv((long)a.D * a.H * a.W, C::V_B);
   const int mtiles = cdiv(a.M, C::M_B);
   MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31) && mtiles <= 65535, "fprop: grid out of range");
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)mtiles), dim3(C::NTHREADS), smem, stream, a);
+  // cross-block K-split: when the (voxel, row) tiles alone cannot fill the chip, slices of the channel axis become blocks too
+  int kz = 1;
+  if (a.kz_part && a.kz_cnt && KZ_OK) {
+    const int nch = cdiv(a.Cin, KC);
+    while (kz * 2 <= nch && tiles * mtiles * kz * 2 <= 256 && kz < 8) kz *= 2;
+    if (kz > 1) {
+      const size_t need = (size_t)tiles * mtiles * kz * (WM * WN * MT * NT) * 1024 * sizeof(float);
+      if (need > kz_part_bytes || (size_t)tiles * mtiles > kz_cnt_entries) kz = 1;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)mtiles, (unsigned)kz), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -37,9 +37,12 @@ struct FpropArgs {
   BnFwd ebn;
   double* dgamma; double* dbeta;                 // [NREP][M]
   StatPtr s_acc;
+  // cross-block K-split (gridDim.z slices of the channel axis): partial tiles + per-tile arrival counters (zero on entry)
+  float* kz_part; unsigned* kz_cnt;
 };
 
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream);
+extern size_t kz_part_bytes, kz_cnt_entries;   // capacity of FpropArgs::kz_part / kz_cnt as provided by the plan
 
 #if defined(__HIPCC__)
 
@@ -66,7 +69,7 @@ struct FpropCfg {
   static size_t smem_bytes(int Cin) {
     int cpad = ((Cin + KC - 1) / KC) * KC;
     size_t ncoef = ((size_t)NCOEF * cpad + 3) & ~(size_t)3;   // keep the staging buffers 16-byte aligned
-    return sizeof(float) * (ncoef + (size_t)BUF + (size_t)ECOEF * M_B);
+    return sizeof(float) * (ncoef + (size_t)BUF + (size_t)ECOEF * M_B + 4);   // + arrival ticket of the cross-block K-split
   }
 };
 
@@ -116,16 +119,20 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   }
   const int m0 = blockIdx.y * M_B;
   const int rep = blockIdx.x & (NREP - 1);
+  // channel slice of this block (cross-block K-split): whole chunks [c_begin, c_end)
+  const int kz = gridDim.z, nch_all = (a.Cin + KC - 1) / KC;
+  const int c_begin = (int)((long)nch_all * blockIdx.z / kz) * KC;
+  const int c_end = min(a.Cin, (int)((long)nch_all * (blockIdx.z + 1) / kz) * KC);
 
   // ---- per-channel prologue coefficients, per-row epilogue coefficients ----
   if (PRO == PRO_BNRELU) {
-    for (int c = tid; c < cpad; c += NTHREADS) {
+    for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
       float ca = 0.f, cb = 0.f, mu, rs;
       if (c < a.Cin) bn_fwd_coef(a.bn_in, c, ca, cb, mu, rs);
       coef[c] = ca; coef[cpad + c] = cb;
     }
   } else if (PRO == PRO_GRAD) {
-    for (int c = tid; c < cpad; c += NTHREADS) {
+    for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
       float p = 0.f, q = 0.f, r = 0.f;
       if (c < a.Cin) {
         bn_bwd_coef(a.gr_in, c, p, q, r);
@@ -348,46 +355,46 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 
     if (SPEC) {
       // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
-      if (loader) { load_chunk(0, stA); store_chunk(0, stA, 0); }
+      if (loader && c_begin < c_end) { load_chunk(c_begin, stA); store_chunk(c_begin, stA, 0); }
       __syncthreads();
       int k = 0;
-      for (int c0 = 0; c0 < a.Cin; c0 += KC, ++k) {
+      for (int c0 = c_begin; c0 < c_end; c0 += KC, ++k) {
         if (loader) {
-          if (c0 + KC < a.Cin) { load_chunk(c0 + KC, stA); store_chunk(c0 + KC, stA, ((k + 1) & 1) * C::STAGE); }
+          if (c0 + KC < c_end) { load_chunk(c0 + KC, stA); store_chunk(c0 + KC, stA, ((k + 1) & 1) * C::STAGE); }
         } else {
           mfma_chunk((k & 1) * C::STAGE);
         }
         __syncthreads();
       }
     } else if (PF == 1) {
-      load_chunk(0, stA);
-      for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+      if (c_begin < c_end) load_chunk(c_begin, stA);
+      for (int c0 = c_begin; c0 < c_end; c0 += KC) {
         store_chunk(c0, stA);
         __syncthreads();
-        if (c0 + KC < a.Cin) load_chunk(c0 + KC, stA);
+        if (c0 + KC < c_end) load_chunk(c0 + KC, stA);
         mfma_chunk();
         __syncthreads();
       }
     } else {
-      load_chunk(0, stA);
-      if (KC < a.Cin) load_chunk(KC, stB);
-      for (int c0 = 0; c0 < a.Cin; c0 += 2 * KC) {
+      if (c_begin < c_end) load_chunk(c_begin, stA);
+      if (c_begin + KC < c_end) load_chunk(c_begin + KC, stB);
+      for (int c0 = c_begin; c0 < c_end; c0 += 2 * KC) {
         store_chunk(c0, stA);
         __syncthreads();
-        if (c0 + 2 * KC < a.Cin) load_chunk(c0 + 2 * KC, stA);
+        if (c0 + 2 * KC < c_end) load_chunk(c0 + 2 * KC, stA);
         mfma_chunk();
         __syncthreads();
-        if (c0 + KC < a.Cin) {
+        if (c0 + KC < c_end) {
           store_chunk(c0 + KC, stB);
           __syncthreads();
-          if (c0 + 3 * KC < a.Cin) load_chunk(c0 + 3 * KC, stB);
+          if (c0 + 3 * KC < c_end) load_chunk(c0 + 3 * KC, stB);
           mfma_chunk();
           __syncthreads();
         }
       }
     }
   } else {
-  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
+  for (int c0 = c_begin; c0 < c_end; c0 += KC) {
     // ================= stage activations =================
     if (TAPS == 27) {
       if (vecx) {
@@ -538,6 +545,52 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
           for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += rbuf[(((g - 1) * WM * WN * MT * NT + slot + i * NT + j) * 16 + r) * 64 + lane];
+    }
+  }
+
+  // ================= cross-block K-split: publish the partial tile; the LAST arriving slice sums all slices (in slice
+  // order: bit-reproducible) and runs the epilogue.  Placement-independent agent-scope release / acquire, no spinning. =======
+  if (kz > 1) {
+    constexpr int NSLOT = WM * WN * MT * NT;
+    const long tile_id = blockIdx.x + (long)gridDim.x * blockIdx.y;
+    float* part = a.kz_part + (tile_id * kz) * NSLOT * 1024;
+    const int slot = (wm * WN + wn) * MT * NT;
+    if (kg == 0 && !loader) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[(((long)blockIdx.z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* ticket = reinterpret_cast<unsigned*>(ecoef + C::ECOEF * M_B);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned arrived = *ticket;
+    if (arrived != (unsigned)(kz - 1)) return;            // not the last slice of this tile: done
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (kg == 0 && !loader) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int z = 0; z < kz; ++z)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += part[(((long)z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane];
+        }
     }
   }
 
