@@ -189,7 +189,8 @@ void plan_free(Plan& p) {
   for (hipEvent_t e : p.sync_ev) (void)hipEventDestroy(e);
   p.sync_ev.clear();
   if (p.side) (void)hipStreamDestroy(p.side);
-  p.side = nullptr;
+  if (p.side2) (void)hipStreamDestroy(p.side2);
+  p.side = p.side2 = nullptr;
 }
 
 static StatPtr statptr(char* ws, size_t o, int C, int off) {
@@ -451,8 +452,10 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     p.side_tried = true;
     const char* off = getenv("MMNN_SINGLE_STREAM");   // debugging / profiling aid: serialise the backward on one stream
     if ((off && off[0] == '1') || hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
+    if (p.side && hipStreamCreateWithFlags(&p.side2, hipStreamNonBlocking) != hipSuccess) p.side2 = nullptr;
   }
-  hipStream_t side = p.side ? p.side : stream;
+  hipStream_t side = p.side ? p.side : stream;                     // conv2 weight gradients (+ the big gradient finalise)
+  hipStream_t side2 = p.side2 ? p.side2 : side;                    // conv1 weight gradients
   const bool two = p.side != nullptr;
   p.sync_used = 0;
   auto next_event = [&]() -> hipEvent_t {
@@ -544,7 +547,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
       { ScopedTimer t(p, T_CONV2_WGRAD, b, side); rc = launch_wgrad(w2, 27, PRO_BNRELU, side); }
       if (rc) return rc;
-      if ((rc = order(stream, side))) return rc;            // dZ2 + dgamma2/dbeta2 ready: side may run conv1 wgrad
+      if ((rc = order(stream, side2))) return rc;           // dZ2 + dgamma2/dbeta2 ready: side2 may run conv1 wgrad
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
@@ -580,12 +583,12 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
       w1.bn = bn1;
       w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
-      { ScopedTimer t(p, T_CONV1_WGRAD, b, side); rc = launch_wgrad(w1, 1, PRO_BNRELU, side); }
+      { ScopedTimer t(p, T_CONV1_WGRAD, b, side2); rc = launch_wgrad(w1, 1, PRO_BNRELU, side2); }
       if (rc) return rc;
       if (two) {
         hipEvent_t e = next_event();
         MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
-        MMNN_HIP(hipEventRecord(e, side));
+        MMNN_HIP(hipEventRecord(e, side2));
         dz_free[dzbuf] = e;
         dzbuf ^= 1;
       }
@@ -633,6 +636,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // stem backward (MFMA-bound) runs here.  Jobs 0..2 of the table are conv0 / norm0 (see build_tables).
       if (two) {
         if ((rc = order(stream, side))) return rc;
+        if (side2 != side && (rc = order(side2, side))) return rc;
         if ((rc = launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad) + 3, p.n_grad_jobs - 3, p.max_grad, grad_params, accumulate, side))) return rc;
       }
       const double cnt0 = (double)N * p.D0 * p.H0 * p.W0;
@@ -662,6 +666,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     }
   }
   if ((rc = order(side, stream))) return rc;                // join: every weight-gradient slab is written / reduced
+  if (side2 != side && (rc = order(side2, stream))) return rc;
   const long stem_count = (long)c.init_features * c.in_channels * 343;
   return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), two ? 3 : p.n_grad_jobs, two ? stem_count : p.max_grad,
                          grad_params, accumulate, stream);

@@ -66,7 +66,7 @@ struct Plan {
   const float* tab_params = nullptr; float* tab_run = nullptr; char* tab_ws = nullptr;
   int n_run_jobs = 0, n_pack_jobs = 0, n_grad_jobs = 0; long max_pack = 0, max_grad = 0;
   // backward runs the weight-gradient kernels on a second stream beside the data-gradient chain (host objects only)
-  hipStream_t side = nullptr; bool side_tried = false;
+  hipStream_t side = nullptr, side2 = nullptr; bool side_tried = false;   // conv2 / conv1 weight-gradient streams
   std::vector<hipEvent_t> sync_ev; size_t sync_used = 0;
   // optional live timing of one kernel class with HIP events (bench.py roofline leg)
   int timer_kind = 0, timer_block = -1;            // kind: see TimerKind; block < 0: every block
