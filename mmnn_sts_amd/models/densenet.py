@@ -75,6 +75,8 @@ class _Backbone(nn.Sequential):
         object.__setattr__(self, "_plans", OrderedDict())
         object.__setattr__(self, "_anchor", None)
         object.__setattr__(self, "_fwd_token", 0)
+        object.__setattr__(self, "_grads_attached", False)
+        object.__setattr__(self, "_grads_stale", True)
 
     # ---- flat parameter storage -------------------------------------------------------------------------------------
     def _bn_modules(self):
@@ -105,21 +107,32 @@ class _Backbone(nn.Sequential):
         object.__setattr__(self, "_flat_nbt", nbt)
         object.__setattr__(self, "_flat_grad", None)
         object.__setattr__(self, "_params", params)
+        object.__setattr__(self, "_bns", bns)
+        object.__setattr__(self, "_grads_attached", False)
+        object.__setattr__(self, "_grads_stale", True)
         object.__setattr__(self, "_anchor", torch.zeros(1, device=dev, requires_grad=True))
         for p in params:
             p.grad = None
 
-    def _storage_ok(self) -> bool:
+    def _storage_ok(self, full: bool = False) -> bool:
+        """Are the parameters still views of the flat buffer?  Per-step check is O(1) (first / last parameter, last running
+        statistic: `.to()`, `.float()`, `load_state_dict(assign=True)` move all of them); `full=True` walks every tensor."""
         flat = self._flat
         if flat is None:
             return False
-        base, off = flat.data_ptr(), 0
-        for p in self._params:
-            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
-                return False
-            off += p.numel()
-        m = self._bn_modules()[-1]
-        return m.running_var.data_ptr() == self._flat_run.data_ptr() + 4 * (self._flat_run.numel() - m.num_features)
+        ps = self._params
+        base = flat.data_ptr()
+        last = self._bns[-1]
+        if (ps[0].data_ptr() != base or ps[-1].data_ptr() != base + 4 * (flat.numel() - ps[-1].numel())
+                or last.running_var.data_ptr() != self._flat_run.data_ptr() + 4 * (self._flat_run.numel() - last.num_features)):
+            return False
+        if full:
+            off = 0
+            for p in ps:
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    return False
+                off += p.numel()
+        return True
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -197,19 +210,30 @@ class _Backbone(nn.Sequential):
                                "later forward of the same module (one live forward per module is supported)")
         params = self._params
         gflat = self._flat_grad
-        fresh = gflat is None or params[0].grad is None or params[0].grad.data_ptr() != gflat.data_ptr()
         if gflat is None:
             gflat = torch.empty_like(self._flat)
             object.__setattr__(self, "_flat_grad", gflat)
+            object.__setattr__(self, "_grads_attached", False)
+        g0 = params[0].grad
+        attached = self._grads_attached and g0 is not None and g0.data_ptr() == gflat.data_ptr()
+        # overwrite when nothing is accumulated yet: gradients dropped by zero_grad(set_to_none=True) of any optimizer, or marked
+        # stale by FusedSGD.zero_grad() (which keeps the views attached: re-attaching 364 tensors per step costs ~1.5 ms of host time)
+        fresh = (not attached) or self._grads_stale
         _lib.check(_lib.lib().mmnn_densenet_backward(ent["plan"], self._flat.data_ptr(), x.data_ptr(), ent["ws"].data_ptr(),
                                                      grad_out.data_ptr(), gflat.data_ptr(), 0 if fresh else 1, seed,
                                                      torch.cuda.current_stream().cuda_stream), "mmnn_densenet_backward")
-        if fresh:   # (re)attach .grad views; afterwards gradients accumulate inside the kernel until zero_grad() drops them
+        if not attached:   # (re)attach .grad views; afterwards gradients accumulate inside the kernel
             off = 0
             for p in params:
                 n = p.numel()
                 p.grad = gflat[off:off + n].view(p.shape)
                 off += n
+            object.__setattr__(self, "_grads_attached", True)
+        object.__setattr__(self, "_grads_stale", False)
+
+    def mark_grads_stale(self) -> None:
+        """The next backward overwrites the flat gradient buffer instead of accumulating (cheap zero_grad)."""
+        object.__setattr__(self, "_grads_stale", True)
 
     # flat views for the fused optimizer / gradient all-reduce
     @property

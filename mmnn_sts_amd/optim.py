@@ -29,8 +29,8 @@ class FusedSGD(torch.optim.Optimizer):
         st = torch.cuda.current_stream().cuda_stream
         for bb in self._backbones:
             flat, grad = bb.flat_parameters, bb.flat_grad
-            if grad is None or bb.conv0.weight.grad is None:
-                continue
+            if grad is None or bb.conv0.weight.grad is None or bb._grads_stale:
+                continue          # no gradient since the last zero_grad()
             first = id(bb) not in self._bufs or self._bufs[id(bb)].data_ptr() == 0 or self._bufs[id(bb)].numel() != flat.numel()
             if first:
                 self._bufs[id(bb)] = torch.empty_like(flat)
@@ -52,10 +52,10 @@ class FusedSGD(torch.optim.Optimizer):
         return None
 
     def zero_grad(self, set_to_none: bool = True):
-        """Backbone gradients are dropped by detaching ONE marker parameter (the next backward overwrites the flat buffer and
-        re-attaches every view); tail gradients are set to None."""
+        """Tail gradients are set to None.  The backbone's `.grad` views stay attached to the flat gradient buffer and are marked
+        stale: the next backward OVERWRITES the buffer (so accumulation semantics are those of zero_grad), without touching 364
+        tensors per step.  Until that backward the stale values remain readable through `.grad`."""
         for bb in self._backbones:
-            for p in bb.parameters():
-                p.grad = None
+            bb.mark_grads_stale()
         for p in self._rest:
             p.grad = None

@@ -303,3 +303,12 @@ def test_dropout_semantics_and_accumulation():
     assert float((bb.flat_grad - g1).abs().max()) > 0
     m.zero_grad(set_to_none=True)
     assert bb.conv0.weight.grad is None
+    h3 = m.backbone(x)
+    h3.sum().backward()                                     # after zero_grad: overwritten, not accumulated; views re-attached
+    assert bb.conv0.weight.grad.data_ptr() == bb.flat_grad.data_ptr()
+    from mmnn_sts_amd.optim import FusedSGD
+    opt = FusedSGD(m, lr=0.0)
+    g3 = bb.flat_grad.clone()
+    opt.zero_grad()                                         # cheap path: views stay attached, buffer marked stale
+    m.backbone(x).sum().backward()
+    assert float((bb.flat_grad.abs().sum() - g3.abs().sum()).abs()) < 0.5 * float(g3.abs().sum())   # same magnitude: not doubled
