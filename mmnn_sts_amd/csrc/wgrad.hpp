@@ -11,6 +11,8 @@
 // Every block owns one (split, channel-group) pair, walks its share of spatial tiles and stores its partial result to
 // slab[split]; slabs are summed by the gradient finaliser (finalize.hip) -- no float atomics, bit-reproducible.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "fprop.hpp"
 
@@ -37,7 +39,8 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin);
 #if defined(__HIPCC__)
 
 // ----------------------------------------------------------------------------------------------------------------
-// 3x3x3:  block = 9 waves (one (kd,kh) pair each, 3 accumulator tiles for kw = 0..2), one 32-channel group of c.
+// 3x3x3:  block = 8 waves sharing the 27 taps 3,3,3,3,3,4,4,4 (two waves per SIMD: 6/7/7/7 tap-units per SIMD, 96 % balanced;
+// 9 waves of 3 taps would put 3 waves on one SIMD and 2 on the others), one 32-channel group of c, <= 4 accumulator tiles per wave.
 // ----------------------------------------------------------------------------------------------------------------
 template <int TD, int TH, int TW>
 struct Wg3Cfg {
@@ -45,14 +48,47 @@ struct Wg3Cfg {
   static constexpr int RS = TW + 2, HS = TH + 2, DS = TD + 2;
   static constexpr int XS = (DS * HS * RS) | 1;      // odd channel stride
   static constexpr int YS = VT + 1;
-  static constexpr int NTHREADS = 9 * 64;
+  static constexpr int NTHREADS = 8 * 64;
   static_assert(VT == 64, "tile must hold 64 voxels (two per MFMA k-step, 32 steps)");
   static_assert(32 % TW == 0, "tile width must divide 32");
   static size_t smem_bytes() { return sizeof(float) * (32 * XS + 32 * YS + 3 * 32 + 2 * 32 + 3 * 32); }
 };
 
+// MFMA over one staged 64-voxel tile for NTP taps: 32 k-steps; the operand reads of step s+1 are issued before the MFMAs of
+// step s (two register sets).  Accumulators are passed by reference so that they stay in registers in both instantiations.
+template <int NTP, int TD, int TH, int TW>
+__device__ __forceinline__ void wg3_mfma(f32x16 (&acc)[4], const float* yl, const float* x0, const float* x1, const float* x2, const float* x3) {
+  constexpr int RS = Wg3Cfg<TD, TH, TW>::RS, HS = Wg3Cfg<TD, TH, TW>::HS;
+  float a0, a1, b0[4], b1[4];
+  auto rd = [&](int s, float& av, float (&bv)[4]) {
+    const int wx = s % TW, hy = (s / TW) % TH, dz = s / (TW * TH);
+    const int p0 = (dz * HS + hy) * RS + wx;
+    av = yl[s];
+    bv[0] = x0[p0]; bv[1] = x1[p0]; bv[2] = x2[p0];
+    if (NTP == 4) bv[3] = x3[p0];
+  };
+  auto mm = [&](float av, const float (&bv)[4]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[1], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[2], acc[2], 0, 0, 0);
+    if (NTP == 4) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[3], acc[3], 0, 0, 0);
+  };
+  rd(0, a0, b0);
+#pragma unroll
+  for (int s = 0; s < 32; s += 2) {
+    rd(s + 1, a1, b1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NTP + 1, 0);
+    mm(a0, b0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NTP, 0);
+    if (s + 2 < 32) rd(s + 2, a0, b0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NTP + 1, 0);
+    mm(a1, b1);
+    __builtin_amdgcn_sched_group_barrier(0x008, NTP, 0);
+  }
+}
+
 template <int PRO_X, int TD, int TH, int TW>
-__global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
   using C = Wg3Cfg<TD, TH, TW>;
   constexpr int RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS, YS = C::YS, NTHREADS = C::NTHREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -78,47 +114,31 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
     if (tid < a.M) bn_bwd_coef(a.gr, tid, p, q, r);
     gbase[tid] = p; gbase[32 + tid] = q; gbase[64 + tid] = r;
   }
-  const int kd = wave / 3, kh = wave % 3;
+  const int tap0 = (wave < 5) ? wave * 3 : 15 + (wave - 5) * 4;       // first tap of this wave
+  const int ntap = (wave < 5) ? 3 : 4;
   // lane-half offset: voxel (s + 32*half) = voxel s shifted by 32/TW rows
   constexpr int ROWS_PER_HALF = 32 / TW;
   const int hrow = half * ROWS_PER_HALF;
   const int hoff = ((hrow / TH) * HS + (hrow % TH)) * RS;
-  const float* xl = Xs + l31 * XS + hoff + (kd * HS + kh) * RS;
+  const float* xb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tap = min(tap0 + j, 26);
+    xb[j] = Xs + l31 * XS + hoff + ((tap / 9) * HS + (tap / 3) % 3) * RS + tap % 3;
+  }
   const float* yl = Ys + l31 * YS + 32 * half;
 
-  f32x16 acc[3];
+  f32x16 acc[4];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // ---- MFMA over one staged tile: 32 k-steps (2 voxels each) x 3 taps; operand reads of step s+1 issued before the
   // MFMAs of step s (two register sets) ----
-  auto mfma_tile = [&]() {
-    auto rd = [&](int s, float& av, float (&bv)[3]) {
-      const int wx = s % TW, hy = (s / TW) % TH, dz = s / (TW * TH);
-      const int p0 = (dz * HS + hy) * RS + wx;
-      av = yl[s];
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) bv[kw] = xl[p0 + kw];
-    };
-    auto mm = [&](float av, const float (&bv)[3]) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kw], acc[kw], 0, 0, 0);
-    };
-    float a0, a1, b0[3], b1[3];
-    rd(0, a0, b0);
-#pragma unroll
-    for (int s = 0; s < 32; s += 2) {
-      rd(s + 1, a1, b1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      mm(a0, b0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-      if (s + 2 < 32) rd(s + 2, a0, b0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      mm(a1, b1);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    }
+  auto mfma_tile = [&]() {   // wave-uniform choice of the tap count
+    if (ntap == 4) wg3_mfma<4, TD, TH, TW>(acc, yl, xb[0], xb[1], xb[2], xb[3]);
+    else wg3_mfma<3, TD, TH, TW>(acc, yl, xb[0], xb[1], xb[2], xb[2]);
   };
   auto tile_origin = [&](int tile, int& n, int& d0, int& h0, int& w0) {
     int b = tile;
@@ -299,12 +319,14 @@ __global__ void __launch_bounds__(576) wgrad3_kernel(const WgradArgs a) {
   // ---- partial result: slab[split][tap][m][c] ----
   float* out = a.slab + (long)split * a.slab_stride;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const int tap = (kd * 3 + kh) * 3 + kw;
+  for (int j = 0; j < 4; ++j) {
+    const int tap = tap0 + j;
+    if (j < ntap) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = acc_row(r, half);
-      if (m < a.M && c0 + l31 < a.Cin) out[((long)tap * a.M + m) * a.Cin + c0 + l31] = acc[kw][r];
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r, half);
+        if (m < a.M && c0 + l31 < a.Cin) out[((long)tap * a.M + m) * a.Cin + c0 + l31] = acc[j][r];
+      }
     }
   }
 }
