@@ -39,6 +39,16 @@ const char* last_error();
     }                                                                                         \
   } while (0)
 
+// Every kernel launch goes through MMNN_LAUNCH.  With MMNN_POISON_LDS=1 in the environment (tests only) each launch is
+// preceded by a kernel that fills the LDS of every CU with NaN bit patterns, so that a kernel which multiplies a
+// zero-padded operand with an LDS entry it never staged shows up as NaN instead of depending on its predecessor.
+void debug_poison_lds(hipStream_t stream);
+#define MMNN_LAUNCH(kern, grid, block, smem, stream, ...)            \
+  do {                                                               \
+    ::mmnn::debug_poison_lds(stream);                                \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__); \
+  } while (0)
+
 // ---- descriptors ----------------------------------------------------------------------------------------------------
 // Statistics of a tensor's channels: sum[r*stride + off + c], sq[...] for replica r.
 struct StatPtr {

@@ -39,7 +39,7 @@ int launch_bnrelu_avgpool(const PoolFwdArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.D >= 2 && a.H >= 2 && a.W >= 2, "avgpool: extent too small (%d,%d,%d)", a.D, a.H, a.W);
   MMNN_REQUIRE(a.N <= 65535 && a.C <= 65535, "avgpool: grid out of range");
   const int Vo = (a.D / 2) * (a.H / 2) * (a.W / 2);
-  hipLaunchKernelGGL(bnrelu_avgpool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_LAUNCH(bnrelu_avgpool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -58,7 +58,7 @@ int launch_bn_apply(const BnApplyArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.V > 0 && a.N <= 65535 && a.C <= 65535, "bn_apply: bad extent");
   int gx = cdiv(a.V, 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_LAUNCH(bn_apply_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -77,7 +77,7 @@ int launch_relu_mask(const MaskArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.V > 0 && a.N <= 65535 && a.C <= 65535 && a.out, "relu_mask: bad arguments");
   int gx = cdiv(a.V, 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(relu_mask_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_LAUNCH(relu_mask_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -126,7 +126,7 @@ int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream) {
   const int V = a.D * a.H * a.W;
   int gx = cdiv(V, 1024);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(consumer_bwd_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_LAUNCH(consumer_bwd_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) running_stats_kernel(const RunStatJob* jo
 
 int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, hipStream_t stream) {
   if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(running_stats_kernel, dim3(njobs), dim3(256), 0, stream, jobs_dev, momentum);
+  MMNN_LAUNCH(running_stats_kernel, dim3(njobs), dim3(256), 0, stream, jobs_dev, momentum);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -191,7 +191,7 @@ int launch_pack(const PackJob* jobs_dev, int njobs, long max_count, hipStream_t 
   int gx = cdiv(max_count, 256 * 4);
   if (gx < 1) gx = 1;
   if (gx > 256) gx = 256;
-  hipLaunchKernelGGL(pack_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev);
+  MMNN_LAUNCH(pack_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -236,7 +236,7 @@ int launch_finalize(const GradJob* jobs_dev, int njobs, long max_count, float* g
   int gx = cdiv(max_count, 256 * 2);
   if (gx < 1) gx = 1;
   if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(finalize_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, grad, accumulate);
+  MMNN_LAUNCH(finalize_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, grad, accumulate);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -274,9 +274,26 @@ int launch_sgd(float* p, const float* g, float* buf, long n, float lr, float mom
   MMNN_REQUIRE(p && g && buf && n > 0, "sgd: bad arguments");
   int gx = cdiv(n, 1024);
   if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(sgd_kernel, dim3(gx), dim3(256), 0, stream, p, g, buf, n, lr, momentum, weight_decay, nesterov, first_step);
+  MMNN_LAUNCH(sgd_kernel, dim3(gx), dim3(256), 0, stream, p, g, buf, n, lr, momentum, weight_decay, nesterov, first_step);
   MMNN_HIP(hipGetLastError());
   return 0;
+}
+
+// ---- debugging aid: poison the LDS of every CU (see MMNN_LAUNCH in common.hpp) -----------------------------------------
+__global__ void __launch_bounds__(256) poison_lds_kernel(int words) {
+  extern __shared__ unsigned poison[];
+  volatile unsigned* q = poison;   // volatile: the stores have no reader in this kernel
+  for (int i = threadIdx.x; i < words; i += 256) q[i] = 0xFFFFFFFFu;   // quiet NaN as fp32, and as either half of an fp64
+}
+
+void debug_poison_lds(hipStream_t stream) {
+  static const int on = [] { const char* e = getenv("MMNN_POISON_LDS"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (!on) return;
+  constexpr int BYTES = 160 * 1024;   // the whole LDS of a CU: one block per CU at a time
+  static const bool ready =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES) == hipSuccess;
+  if (!ready) return;
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), BYTES, stream, BYTES / 4);
 }
 
 }  // namespace mmnn

@@ -32,7 +32,8 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31) && mtiles <= 65535, "fprop: grid out of range");
   // cross-block K-split: when the (voxel, row) tiles alone cannot fill the chip, slices of the channel axis become blocks too
   int kz = 1;
-  if (a.kz_part && a.kz_cnt && KZ_OK) {
+  static const bool kz_off = []() { const char* e = getenv("MMNN_NO_KZ"); return e && e[0] == '1'; }();   // debugging aid
+  if (a.kz_part && a.kz_cnt && KZ_OK && !kz_off) {
     const int nch = cdiv(a.Cin, KC);
     while (kz * 2 <= nch && tiles * mtiles * kz * 2 <= 256 && kz < 8) kz *= 2;
     if (kz > 1) {
@@ -40,7 +41,7 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
       if (need > kz_part_bytes || (size_t)tiles * mtiles > kz_cnt_entries) kz = 1;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)mtiles, (unsigned)kz), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_LAUNCH(kern, dim3((unsigned)tiles, (unsigned)mtiles, (unsigned)kz), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -65,7 +66,11 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
     if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
   }
-  if (a.W > 16) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);   // 2 blocks/CU overlap better than loader waves here
+  if (a.W > 16) {
+    static const char* e = getenv("MMNN_DGRAD_KC");   // experiment knob
+    if (e && e[0] == '2') return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
+    return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);   // 2 blocks/CU overlap better than loader waves here
+  }
   if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
   if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);
   return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 2, 4, 4>(a, s);

@@ -52,11 +52,13 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
   for (int kd = 0; kd < 7; ++kd) {
     __syncthreads();
     // ---- stage input planes d_in = 2*(do0+dz) + kd - 3 ----
-    const int items = a.Cin * SC_TD * SC_ROWS * 69;
+    // 70 columns per row: the odd-Cin path pairs taps (kw, kw+1) across lane halves, so its zero-weight pad tap kw = 7
+    // reads parity-1 entry l31 + 3 <= 34; that entry must hold a finite value (0 * garbage-NaN would poison the tile).
+    const int items = a.Cin * SC_TD * SC_ROWS * 70;
 #pragma unroll 8
     for (int it = tid; it < items; it += 256) {
-      const int ci = it % 69;
-      int row = it / 69;
+      const int ci = it % 70;
+      int row = it / 70;
       const int r = row % SC_ROWS; row /= SC_ROWS;
       const int dz = row % SC_TD;
       const int c = row / SC_TD;
@@ -171,7 +173,7 @@ int launch_stem_conv(const StemConvArgs& a, hipStream_t stream) {
   const bool pair_c = (a.Cin % 2 == 0);
   auto kern = pair_c ? stem_conv_kernel<true> : stem_conv_kernel<false>;
   MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, a);
+  MMNN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -230,7 +232,7 @@ int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "stem pool: bad extent");
   MMNN_REQUIRE(a.Do == (a.Di - 1) / 2 + 1 && a.Ho == (a.Hi - 1) / 2 + 1 && a.Wo == (a.Wi - 1) / 2 + 1, "stem pool: output extent mismatch");
   const int Vo = a.Do * a.Ho * a.Wo;
-  hipLaunchKernelGGL(stem_pool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
+  MMNN_LAUNCH(stem_pool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -315,7 +317,7 @@ int launch_stem_pool_bwd(const StemPoolBwdArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)PB_PD * PB_PH * a.Wo * 8;
   MMNN_REQUIRE(smem <= 64 * 1024, "stem pool bwd: row too wide (%d)", a.Wo);
   const int blocks = cdiv(a.Di, PB_TD) * cdiv(a.Hi, PB_TH);
-  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(blocks, a.C, a.N), dim3(256), smem, stream, a);
+  MMNN_LAUNCH(stem_pool_bwd_kernel, dim3(blocks, a.C, a.N), dim3(256), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -471,7 +473,7 @@ int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo) {
 int launch_stem_wgrad(const StemWgradArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cin <= 65535 && a.M > 0 && a.M <= 64, "stem wgrad: bad extent");
   MMNN_REQUIRE(a.nsplit >= 1 && a.slab_stride >= (long)a.Cin * a.M * 352, "stem wgrad: bad slab layout");
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(a.nsplit, a.Cin), dim3(SW_THREADS), 0, stream, a);
+  MMNN_LAUNCH(stem_wgrad_kernel, dim3(a.nsplit, a.Cin), dim3(SW_THREADS), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

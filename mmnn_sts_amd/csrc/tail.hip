@@ -416,8 +416,8 @@ int mmnn_gap_linear_forward(int32_t n, int32_t c, int32_t v, int32_t f, const fl
   MMNN_REQUIRE(n > 0 && c > 0 && v > 0 && f > 0 && n <= 65535 && h && w && b && pooled && out, "gap_linear_forward: bad arguments");
   GapArgs a{n, c, v, f, h, w, b, pooled, out, p, seed, training};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gap_kernel, dim3(cdiv(c, 4), n), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(gap_linear_kernel, dim3(1), dim3(256), 0, s, a);
+  MMNN_LAUNCH(gap_kernel, dim3(cdiv(c, 4), n), dim3(256), 0, s, a);
+  MMNN_LAUNCH(gap_linear_kernel, dim3(1), dim3(256), 0, s, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -427,7 +427,7 @@ int mmnn_gap_linear_backward(int32_t n, int32_t c, int32_t v, int32_t f, const f
                              int32_t accumulate, void* stream) {
   MMNN_REQUIRE(n > 0 && c > 0 && v > 0 && f > 0 && n <= 65535 && c <= 65535 && h && w && pooled && dout && dw && db && dh, "gap_linear_backward: bad arguments");
   GapBwdArgs a{n, c, v, f, h, w, pooled, dout, dw, db, dh, p, seed, training, accumulate};
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(c, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMNN_LAUNCH(gap_bwd_kernel, dim3(c, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -461,7 +461,7 @@ int mmnn_mlp_forward(const mmnn_mlp_desc* d, const mmnn_mlp_params* p, const flo
   MMNN_REQUIRE(x && out && saved, "mlp_forward: null buffer");
   MMNN_REQUIRE(!(d->training && d->n < 2), "mlp_forward: batch norm in training mode needs more than 1 value per channel (N=%d)", d->n);
   a.x = x; a.out = out; a.saved = saved;
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMNN_LAUNCH(mlp_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -473,7 +473,7 @@ int mmnn_mlp_backward(const mmnn_mlp_desc* d, const mmnn_mlp_params* p, const fl
   MMNN_REQUIRE(x && saved && dy && scratch, "mlp_backward: null buffer");
   for (int i = 0; i < a.nl; ++i) MMNN_REQUIRE(a.dw[i] && a.db[i] && a.dgamma[i] && a.dbeta[i], "mlp_backward: null gradient pointer in layer %d", i);
   a.x = x; a.saved = const_cast<float*>(saved); a.dy = dy; a.dx = dx; a.scratch = scratch; a.accumulate = accumulate;
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMNN_LAUNCH(mlp_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -485,7 +485,7 @@ int mmnn_fusion_heads_forward(int32_t n, int32_t f, int32_t c, int32_t blend, co
   HeadsArgs a;
   memset(&a, 0, sizeof(a));
   a.N = n; a.F = f; a.C = c; a.blend = blend; a.fi = fi; a.fc = fc; a.wf = wf; a.bf = bf; a.wi = wi; a.bi = bi; a.wc = wc; a.bc = bc; a.out = out;
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMNN_LAUNCH(heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -499,7 +499,7 @@ int mmnn_fusion_heads_backward(int32_t n, int32_t f, int32_t c, int32_t blend, c
   memset(&a, 0, sizeof(a));
   a.N = n; a.F = f; a.C = c; a.blend = blend; a.fi = fi; a.fc = fc; a.wf = wf; a.wi = wi; a.wc = wc; a.dout = dout;
   a.dfi = dfi; a.dfc = dfc; a.dwf = dwf; a.dbf = dbf; a.dwi = dwi; a.dbi = dbi; a.dwc = dwc; a.dbc = dbc; a.accumulate = accumulate;
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MMNN_LAUNCH(heads_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -508,7 +508,7 @@ int mmnn_linear_forward(int32_t n, int32_t d, int32_t o, const float* x, const f
   MMNN_REQUIRE(n > 0 && d > 0 && o > 0 && x && w && y, "linear_forward: bad arguments");
   int g = cdiv((long)n * o, 256);
   if (g > 64) g = 64;
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), n, d, o, x, w, b, y);
+  MMNN_LAUNCH(linear_fwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), n, d, o, x, w, b, y);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -518,7 +518,7 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
   MMNN_REQUIRE(n > 0 && d > 0 && o > 0 && x && w && dy && dw, "linear_backward: bad arguments");
   int g = cdiv(std::max((long)n * d, (long)o * d), 256);
   if (g > 64) g = 64;
-  hipLaunchKernelGGL(linear_bwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), n, d, o, x, w, dy, dx, dw, db, accumulate);
+  MMNN_LAUNCH(linear_bwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), n, d, o, x, w, dy, dx, dw, db, accumulate);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -532,7 +532,7 @@ int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds,
   a.H = heads; a.N = n; a.C = c; a.preds = preds; a.key = reinterpret_cast<const long long*>(sort_key);
   a.wgt = reinterpret_cast<const long long*>(weight); a.hw = head_weights; a.head_loss = head_losses; a.loss = loss;
   a.grad = grad_preds; a.scratch = scratch; a.eps = 1e-7f;
-  hipLaunchKernelGGL(cox_kernel, dim3(1), dim3(256), 0, s, a);
+  MMNN_LAUNCH(cox_kernel, dim3(1), dim3(256), 0, s, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -28,7 +28,8 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
   const int wc = wg1_wc(Cin);
   const long waves_per_split = (long)cdiv(Cin, 32 * wc) * wc * cdiv(M, 128);
   long s = 2048 / waves_per_split;
-  if (s > 64) s = 64;
+  const long cap = waves_per_split <= 2 ? 256 : (waves_per_split <= 4 ? 128 : 64);   // few channels: more voxel splits (small slabs)
+  if (s > cap) s = cap;
   if (s > nchunks / 2) s = nchunks / 2;
   return s < 1 ? 1 : (int)s;
 }
@@ -43,7 +44,7 @@ static int launch3(const WgradArgs& a, hipStream_t stream) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nsplit, cdiv(a.Cin, 32)), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32)), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -58,7 +59,7 @@ static int launch1(const WgradArgs& a, hipStream_t stream) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -9,6 +9,7 @@ through the C-ABI (include/mmnn_sts.h).  The torch.nn sub-modules below are PARA
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 from typing import Sequence, Union
 
@@ -161,6 +162,8 @@ class _Backbone(nn.Sequential):
         shp = [ctypes.c_int32() for _ in range(4)]
         _lib.check(L.mmnn_densenet_out_shape(plan, *[ctypes.byref(v) for v in shp]), "out_shape")
         ws = torch.empty(L.mmnn_densenet_workspace_bytes(plan), dtype=torch.uint8, device=x.device)
+        if os.environ.get("MMNN_POISON_WS") == "1":   # debugging aid: NaN-fill so reads of unwritten workspace words surface
+            ws.fill_(255)
         ent = {"plan": plan, "ws": ws, "out_shape": (n,) + tuple(v.value for v in shp)}
         self._plans[key] = ent
         while len(self._plans) > self._MAX_PLANS:

@@ -38,7 +38,8 @@ class NativeBackbone:
         self.out_shape = (n,) + tuple(v.value for v in c)
         self.device = device
         self.in_dhw = (d, h, w)
-        self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
+        # adversarial fill: every fp32 / fp64 word of the workspace starts as NaN, so a kernel that reads a word nobody wrote shows up
+        self.ws = torch.full((self.ws_bytes,), 255, dtype=torch.uint8, device=device)
         self.schema = R.densenet_schema(cfg)
 
     def __del__(self):

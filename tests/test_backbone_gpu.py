@@ -114,3 +114,32 @@ def test_backbone_accumulate_and_eval():
     g3 = nb.backward(flat, x.cuda(), cot)
     torch.cuda.synchronize()
     assert rel_err(g3.cpu().numpy(), g1.cpu().numpy()) < 1e-5 and rel_err(out2.cpu().numpy(), out.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_ch", [1, 2])
+def test_backbone_repeated_calls_are_bit_identical(in_ch):
+    """One plan, many calls: every forward / backward of the same inputs must reproduce the first bit for bit, whatever ran
+    before it (the kernels keep no state between calls and never read LDS or workspace words they did not write)."""
+    from tests._native import NativeBackbone
+    cfg = R.DenseNetCfg(in_channels=in_ch)
+    n, s = 2, 64
+    nb = NativeBackbone(cfg, n, s, s, s)
+    flat, run = nb.flatten(synth_sd(R.densenet_schema(cfg), "densenet."))
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(n, in_ch, s, s, s, device="cuda", generator=g)
+    cot = torch.randn(nb.out_shape, device="cuda", generator=g)
+    ref_o = ref_g = None
+    for op in "FFBFBBFFB":
+        if op == "F":
+            o = nb.forward(flat, run.clone(), x, True, seed=1)
+            assert torch.isfinite(o).all()
+            if ref_o is None:
+                ref_o = o
+            assert torch.equal(o, ref_o), f"forward deviates by {float((o - ref_o).abs().max())}"
+        else:
+            gr = nb.backward(flat, x, cot, seed=1)
+            assert torch.isfinite(gr).all()
+            if ref_g is None:
+                ref_g = gr
+            assert torch.equal(gr, ref_g), f"backward deviates by {float((gr - ref_g).abs().max())}"
