@@ -1,6 +1,7 @@
 // Launch plan of the DenseNet backbone forward / backward (see densenet.hpp).
 #include "densenet.hpp"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -89,12 +90,11 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   p.o_conv0 = cv.take((size_t)N * cfg.init_features * V0 * F);
   p.o_idx = cv.take((size_t)N * cfg.init_features * p.Vb[0]);
   p.o_t1.assign(nb, {});
-  size_t dz2 = 0, dap = 0;
+  size_t dap = 0;
   for (int b = 0; b < nb; ++b) {
     p.o_x[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b] * F);
     p.o_g[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b] * F);
     for (int l = 0; l < cfg.block_layers[b]; ++l) p.o_t1[b].push_back(cv.take((size_t)N * p.mid * p.Vb[b] * F));
-    dz2 = std::max(dz2, (size_t)N * p.mid * p.Vb[b] * F);
     if (b != nb - 1) {
       p.o_ap[b] = cv.take((size_t)N * p.ctot_b[b] * p.Vb[b + 1] * F);
       dap = std::max(dap, (size_t)N * p.ctot_b[b] * p.Vb[b + 1] * F);
@@ -102,8 +102,6 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
       p.o_ap[b] = 0;
     }
   }
-  p.o_dz2 = cv.take(dz2);
-  p.o_dz2b = cv.take(dz2);
   p.o_dap = cv.take(dap ? dap : 256);
   p.o_dz0 = cv.take((size_t)N * cfg.init_features * V0 * F);
   // forward statistics (fp64, zeroed at the start of every training forward)
@@ -161,6 +159,9 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
       p.o_sl_tr.push_back(cv.take((size_t)s * p.trans[b].cout * p.trans[b].cin * F));
     }
   }
+  // dZ2 (gradient wrt the norm2 output) of every layer has its own buffer: the conv1 weight gradients that read it run on a
+  // side stream, several layers behind the data-gradient chain, and must never make the chain wait for a buffer.
+  for (int b = 0; b < nb; ++b) p.o_dz2[b] = cv.take((size_t)cfg.block_layers[b] * N * p.mid * p.Vb[b] * F);
   // cross-block K-split scratch: <= 256 blocks x one 32x32 (or 4 x 32x32) partial tile each, + per-tile counters
   constexpr size_t KZ_PART = (size_t)512 * 4 * 1024 * sizeof(float), KZ_CNT = 4096;
   p.o_kz_part = cv.take(KZ_PART);
@@ -253,6 +254,9 @@ static void build_tables(Plan& p, const float* params, float* run, char* ws) {
   grad_bn(p.o_dg_n0, c.init_features, p.p_n0w, p.p_n0b);
   for (int b = 0; b < nb; ++b) {
     const double cnt = (double)p.N * p.Vb[b];
+    p.gj_begin[b] = ig;
+    const long max_before = p.max_grad;
+    p.max_grad = 0;
     for (int l = 0; l < c.block_layers[b]; ++l) {
       const LayerOff& lo = p.layers[b][l];
       run_job(p.o_st_x[b], p.ctot_b[b], 0, lo.cin, lo.r1m, lo.r1v, cnt);
@@ -275,7 +279,10 @@ static void build_tables(Plan& p, const float* params, float* run, char* ws) {
       run_job(p.o_st_x[b], p.ctot_b[b], 0, p.ctot_b[b], p.r_n5m, p.r_n5v, cnt);
       grad_bn(p.o_dg_n5, p.ctot_b[b], p.p_n5w, p.p_n5b);
     }
+    p.gj_max[b] = p.max_grad;
+    p.max_grad = std::max(p.max_grad, max_before);
   }
+  p.gj_begin[nb] = ig;
   p.n_run_jobs = ir; p.n_pack_jobs = ip; p.n_grad_jobs = ig;
   p.tab_params = params; p.tab_run = run; p.tab_ws = ws;
 }
@@ -475,8 +482,40 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     MMNN_HIP(hipStreamWaitEvent(to, e, 0));
     return 0;
   };
-  hipEvent_t dz_free[2] = {nullptr, nullptr};   // side stream finished reading dz2 buffer i
-  int dzbuf = 0;
+  // Weight gradients are launched in groups of `grp` layers: one event record on the main stream per group.  Every record
+  // costs the chain ~6 us (the next kernel waits for the barrier packet's signal instead of being chained by the command
+  // processor), which is as long as a whole small-block kernel, so blocks 2-4 batch several layers per record.
+  struct PendingW { WgradArgs w2, w1; int b; };
+  std::vector<PendingW> pend;
+  static int grp_cfg[3] = {1, 2, 4};   // layers per group for >= 32768 / >= 4096 / fewer voxels per batch
+  static const bool grp_init = [] {
+    const char* e = getenv("MMNN_WGRAD_GROUP");   // experiment knob: "a,b,c"
+    if (e) sscanf(e, "%d,%d,%d", &grp_cfg[0], &grp_cfg[1], &grp_cfg[2]);
+    for (int& g : grp_cfg) g = g < 1 ? 1 : g;
+    return true;
+  }();
+  (void)grp_init;
+  auto flush = [&]() -> int {
+    if (pend.empty()) return 0;
+    int rc2;
+    if (two) {
+      hipEvent_t e = next_event();
+      MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
+      MMNN_HIP(hipEventRecord(e, stream));
+      MMNN_HIP(hipStreamWaitEvent(side, e, 0));
+      if (side2 != side) MMNN_HIP(hipStreamWaitEvent(side2, e, 0));
+    }
+    for (const PendingW& q : pend) {
+      { ScopedTimer t(p, T_CONV2_WGRAD, q.b, side); rc2 = launch_wgrad(q.w2, 27, PRO_BNRELU, side); }
+      if (rc2) return rc2;
+    }
+    for (const PendingW& q : pend) {
+      { ScopedTimer t(p, T_CONV1_WGRAD, q.b, side2); rc2 = launch_wgrad(q.w1, 1, PRO_BNRELU, side2); }
+      if (rc2) return rc2;
+    }
+    pend.clear();
+    return 0;
+  };
   auto sptr = [&](int b, int off) { return statptr(ws, p.o_s_x[b], p.ctot_b[b], off); };
   auto concat_grad = [&](int b, int off) {   // BN-backward of concat channels [off, ...) of block b (gammas folded into G)
     BnBwd g;
@@ -506,6 +545,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     const double cnt = (double)N * p.Vb[b];
     const long xns = (long)p.ctot_b[b] * p.Vb[b];
     const long tns = (long)p.mid * p.Vb[b];
+    const long nvox = (long)N * p.Vb[b];
+    const int grp = grp_cfg[nvox >= 32768 ? 0 : nvox >= 4096 ? 1 : 2];
     for (int l = c.block_layers[b] - 1; l >= 0; --l) {
       --layer_id;
       const LayerOff& lo = p.layers[b][l];
@@ -525,9 +566,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       a.gr_in = concat_grad(b, lo.cin);
       a.drop_in = drop;
       a.w = fptr(ws, p.o_pk_c2b[b][l]); a.w_ld = p.mid;
-      float* dz2 = fptr(ws, dzbuf ? p.o_dz2b : p.o_dz2);
-      if ((rc = order(stream, side))) return rc;            // G slice of this layer is complete: side may start conv2 wgrad
-      if (two && dz_free[dzbuf]) MMNN_HIP(hipStreamWaitEvent(stream, dz_free[dzbuf], 0));   // buffer reuse
+      float* dz2 = fptr(ws, p.o_dz2[b]) + (long)l * N * tns;
       a.out = dz2; a.out_ns = tns; a.out_coff = 0;
       a.ex = fptr(ws, p.o_t1[b][l]); a.ex_ns = tns; a.ex_coff = 0;
       a.ebn = bn2;
@@ -545,9 +584,6 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
       w2.bn = bn2;
       w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
-      { ScopedTimer t(p, T_CONV2_WGRAD, b, side); rc = launch_wgrad(w2, 27, PRO_BNRELU, side); }
-      if (rc) return rc;
-      if ((rc = order(stream, side2))) return rc;           // dZ2 + dgamma2/dbeta2 ready: side2 may run conv1 wgrad
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
@@ -583,15 +619,22 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
       w1.bn = bn1;
       w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
-      { ScopedTimer t(p, T_CONV1_WGRAD, b, side2); rc = launch_wgrad(w1, 1, PRO_BNRELU, side2); }
-      if (rc) return rc;
-      if (two) {
-        hipEvent_t e = next_event();
-        MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
-        MMNN_HIP(hipEventRecord(e, side2));
-        dz_free[dzbuf] = e;
-        dzbuf ^= 1;
+      // both weight gradients of this layer can run from here on (its G slice was final before conv2 dgrad, dZ2 and
+      // dgamma2/dbeta2 since conv2 dgrad): queue them for the side streams
+      PendingW pw;
+      pw.w2 = w2; pw.w1 = w1; pw.b = b;
+      pend.push_back(pw);
+      if ((int)pend.size() >= grp || l == 0) {
+        if ((rc = flush())) return rc;
       }
+    }
+    if (two) {
+      // Every gradient of this block (its layers, and the transition / norm5 that consumed it) is final once the side streams
+      // drain: reduce its slabs there (HBM-bound) while the chain moves on to the next block / the stem (MFMA-bound).
+      if ((rc = order(stream, side))) return rc;
+      if (side2 != side && (rc = order(side2, side))) return rc;
+      if ((rc = launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad) + p.gj_begin[b], p.gj_begin[b + 1] - p.gj_begin[b],
+                                p.gj_max[b], grad_params, accumulate, side))) return rc;
     }
     if (b > 0) {
       const int pb = b - 1;
@@ -632,13 +675,6 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       q.s_acc = sptr(pb, 0);
       if ((rc = launch_consumer_bwd(q, stream))) return rc;
     } else {
-      // Everything except the stem's own gradients is final now: reduce those slabs on the side stream (HBM-bound) while the
-      // stem backward (MFMA-bound) runs here.  Jobs 0..2 of the table are conv0 / norm0 (see build_tables).
-      if (two) {
-        if ((rc = order(stream, side))) return rc;
-        if (side2 != side && (rc = order(side2, side))) return rc;
-        if ((rc = launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad) + 3, p.n_grad_jobs - 3, p.max_grad, grad_params, accumulate, side))) return rc;
-      }
       const double cnt0 = (double)N * p.D0 * p.H0 * p.W0;
       StemPoolBwdArgs q;
       q.N = N; q.C = c.init_features; q.Di = p.D0; q.Hi = p.H0; q.Wi = p.W0; q.Do = p.Db[0]; q.Ho = p.Hb[0]; q.Wo = p.Wb[0];
@@ -714,7 +750,7 @@ long plan_ws_offset(const Plan& p, const char* name, int i, int j) {
   if (s == "conv0") return (long)p.o_conv0;
   if (s == "idx") return (long)p.o_idx;
   if (s == "dz0") return (long)p.o_dz0;
-  if (s == "dz2") return (long)p.o_dz2;
+  if (s == "dz2" && okl(i, j)) return (long)(p.o_dz2[i] + (size_t)j * p.N * p.mid * p.Vb[i] * sizeof(float));
   if (s == "dap") return (long)p.o_dap;
   if (s == "x" && okb(i)) return (long)p.o_x[i];
   if (s == "g" && okb(i)) return (long)p.o_g[i];

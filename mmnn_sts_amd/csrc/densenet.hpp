@@ -39,7 +39,7 @@ struct Plan {
   int n_bn;
   // workspace (byte offsets)
   size_t ws_bytes;
-  size_t o_conv0, o_idx, o_x[MAX_BLOCKS], o_g[MAX_BLOCKS], o_ap[MAX_BLOCKS], o_dz2, o_dz2b, o_dap, o_dz0;
+  size_t o_conv0, o_idx, o_x[MAX_BLOCKS], o_g[MAX_BLOCKS], o_ap[MAX_BLOCKS], o_dz2[MAX_BLOCKS], o_dap, o_dz0;
   std::vector<std::vector<size_t>> o_t1;
   // fp64 statistics: one zero-filled region for forward sums, one for backward sums
   size_t o_fstat, fstat_bytes, o_bstat, bstat_bytes;
@@ -65,6 +65,8 @@ struct Plan {
   // cached identity of the buffers the tables were built for
   const float* tab_params = nullptr; float* tab_run = nullptr; char* tab_ws = nullptr;
   int n_run_jobs = 0, n_pack_jobs = 0, n_grad_jobs = 0; long max_pack = 0, max_grad = 0;
+  int gj_begin[MAX_BLOCKS + 1] = {0};   // gradient jobs of block b: [gj_begin[b], gj_begin[b+1])  (jobs 0..2: the stem)
+  long gj_max[MAX_BLOCKS] = {0};        // largest job of the block
   // backward runs the weight-gradient kernels on a second stream beside the data-gradient chain (host objects only)
   hipStream_t side = nullptr, side2 = nullptr; bool side_tried = false;   // conv2 / conv1 weight-gradient streams
   std::vector<hipEvent_t> sync_ev; size_t sync_used = 0;

@@ -67,9 +67,11 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
   }
   if (a.W > 16) {
+    // KC = 2: the smallest chunk (one MFMA k-pair per tap) keeps the LDS footprint low enough for 3-4 blocks per CU, which
+    // hides the staging latency better than loader waves or a deeper chunk do here (194 -> 173 us at block 1).
     static const char* e = getenv("MMNN_DGRAD_KC");   // experiment knob
-    if (e && e[0] == '2') return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
-    return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);   // 2 blocks/CU overlap better than loader waves here
+    if (e && e[0] == '4') return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 4, 1, 4, 32>(a, s);
+    return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
   }
   if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
   if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);

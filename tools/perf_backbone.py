@@ -19,13 +19,18 @@ flat, run = nb.flatten(synth_sd(R.densenet_schema(cfg), "densenet."))
 x = torch.randn(n, 2, s, s, s, device="cuda")
 cot = torch.randn(nb.out_shape, device="cuda")
 grad = torch.zeros_like(flat)
+torch.cuda.synchronize()
+if os.environ.get('OWN_STREAM') == '1':
+    torch.cuda.set_stream(torch.cuda.Stream())
 for _ in range(2):
     nb.forward(flat, run, x, True, seed=1)
     nb.backward(flat, x, cot, grad=grad, seed=1)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tf = tb = 0.0
+pause = float(os.environ.get('PAUSE_MS', '0')) / 1e3
 for _ in range(iters):
+    if pause: time.sleep(pause)
     ev[0].record()
     nb.forward(flat, run, x, True, seed=1)
     ev[1].record()
