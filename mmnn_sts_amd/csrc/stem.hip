@@ -241,10 +241,10 @@ int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
 // Backward of BN+ReLU+max-pool:  dz[q] = relu'(q) * sum over windows p whose argmax is q of dP[p],
 // dP = BN-backward(G, pooled) on the fly;  also dgamma0 / dbeta0 sums.
 // =====================================================================================================================
-// One block = (n, c, 2 x 8 rows of the conv-output grid, full width).  The <= 2 x 5 x Wo pooled windows that can route a
+// One block = (n, c, 8 x 8 rows of the conv-output grid, full width).  The <= 5 x 5 x Wo pooled windows that can route a
 // gradient into those rows are staged in LDS once (dP evaluated on the fly + winning tap), then every fine voxel gathers its
 // <= 8 candidates from LDS with branch-free selects: deterministic (no atomics on the tensor), every global load batched.
-constexpr int PB_TD = 2, PB_TH = 8, PB_PD = 2, PB_PH = 5;
+constexpr int PB_TD = 8, PB_TH = 8, PB_PD = 5, PB_PH = 5;
 
 __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float pb_smem[];
@@ -275,12 +275,8 @@ __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArg
   }
   __syncthreads();
   float s0 = 0.f, s1 = 0.f;
-  const int nq = PB_TD * PB_TH * a.Wi;
-  for (int i = threadIdx.x; i < nq; i += 256) {
-    const int w = i % a.Wi, h = h0 + (i / a.Wi) % PB_TH, d = d0 + i / (a.Wi * PB_TH);
-    const bool inq = d < a.Di && h < a.Hi;
-    const long q = inq ? ((long)d * a.Hi + h) * a.Wi + w : 0;
-    const float x = xc[q];
+  // gradient routed into fine voxel (d, h, w): gather its <= 8 candidate windows from LDS
+  auto route = [&](int d, int h, int w) -> float {
     // candidate windows along each axis: even coordinate -> (p = q/2, k = 1); odd -> (p = (q+1)/2, k = 0) and (p = (q-1)/2, k = 2)
     const int od = d & 1, oh = h & 1, ow = w & 1;
     const int pdA = (d + 1) / 2 - pd0, kdA = od ? 0 : 1, pdB = (d - 1) / 2 - pd0;   // B valid only for odd coordinates (k = 2)
@@ -297,9 +293,39 @@ __global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const StemPoolBwdArg
       const bool hit = valid && tapw[li] == kd * 9 + kh * 3 + kw;
       z += hit ? dP[li] : 0.f;
     }
-    z = (inq && fmaf(ca, x, cb) > 0.f) ? z : 0.f;
-    if (inq) a.dz[((long)n * a.C + c) * Vi + q] = z;
-    s0 += z; s1 += z * (x - mu) * rs;
+    return z;
+  };
+  float* dzc = a.dz + ((long)n * a.C + c) * Vi;
+  if ((a.Wi & 3) == 0 && ((((uintptr_t)xc | (uintptr_t)dzc) & 15) == 0)) {
+    // four consecutive voxels of a row per item: one 16-byte load / store each
+    const int wq = a.Wi / 4, nq4 = PB_TD * PB_TH * wq;
+    for (int i = threadIdx.x; i < nq4; i += 256) {
+      const int w0 = (i % wq) * 4, h = h0 + (i / wq) % PB_TH, d = d0 + i / (wq * PB_TH);
+      const bool inq = d < a.Di && h < a.Hi;
+      const long q = inq ? ((long)d * a.Hi + h) * a.Wi + w0 : 0;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xc + q);
+      f32x4 zv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = route(d, h, w0 + e);
+        z = (inq && fmaf(ca, x[e], cb) > 0.f) ? z : 0.f;
+        zv[e] = z;
+        s0 += z; s1 += z * (x[e] - mu) * rs;
+      }
+      if (inq) *reinterpret_cast<f32x4*>(dzc + q) = zv;
+    }
+  } else {
+    const int nq = PB_TD * PB_TH * a.Wi;
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const int w = i % a.Wi, h = h0 + (i / a.Wi) % PB_TH, d = d0 + i / (a.Wi * PB_TH);
+      const bool inq = d < a.Di && h < a.Hi;
+      const long q = inq ? ((long)d * a.Hi + h) * a.Wi + w : 0;
+      const float x = xc[q];
+      float z = route(d, h, w);
+      z = (inq && fmaf(ca, x, cb) > 0.f) ? z : 0.f;
+      if (inq) dzc[q] = z;
+      s0 += z; s1 += z * (x - mu) * rs;
+    }
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   const int wave = threadIdx.x >> 6;

@@ -26,10 +26,14 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
   const long V = (long)D * H * W;
   const long nchunks = (long)N * cdiv(V, 64);
   const int wc = wg1_wc(Cin);
-  const long waves_per_split = (long)cdiv(Cin, 32 * wc) * wc * cdiv(M, 128);
-  long s = 2048 / waves_per_split;
-  const long cap = waves_per_split <= 2 ? 256 : (waves_per_split <= 4 ? 128 : 64);   // few channels: more voxel splits (small slabs)
-  if (s > cap) s = cap;
+  // Each block owns a (128 x 32*wc) tile of the weight gradient and loops over its share of the 64-voxel chunks; a chunk
+  // costs ~3.4 us of MFMA per CU, so the splits are chosen to give every CU about two blocks (one staging while the other
+  // multiplies), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
+  static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  const long groups = (long)cdiv(Cin, 32 * wc) * cdiv(M, 128);
+  long s = target / groups;
+  const long slab_cap = ((long)64 << 20) / ((long)M * Cin * 4);
+  if (s > slab_cap) s = slab_cap;
   if (s > nchunks / 2) s = nchunks / 2;
   return s < 1 ? 1 : (int)s;
 }
