@@ -56,18 +56,10 @@ static int dispatch(const FpropArgs& a, hipStream_t s) {
   if (TAPS == 1) {
     const long blocks_a = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
     const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
-    static const int kc_a = [] { const char* e = getenv("MMNN_1X1_KC_A"); return e ? atoi(e) : 16; }();   // experiment knobs
-    static const int kc_b = [] { const char* e = getenv("MMNN_1X1_KC_B"); return e ? atoi(e) : 64; }();
-    if (blocks_a >= 192) {
-      if (kc_a == 32) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 32, 1, 1, 128>(a, s);
-      if (kc_a == 8) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 8, 1, 1, 128>(a, s);
-      return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
-    }
-    if (blocks_b >= 192) {
-      if (kc_b == 16) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 16, 1, 1, 64>(a, s);
-      if (kc_b == 128) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 128, 1, 1, 64>(a, s);
-      return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 64, 1, 1, 64>(a, s);   // deep chunks: 4x fewer barriers than KC = 16 (25 -> 17 us at 16^3)
-    }
+    // 128-wide tile: KC = 8 / 16 / 32 measure the same (37 us at 32^3: a fixed ~17 us of prologue, output write and statistics,
+    // then 0.15 us per input channel = 115 TFLOP/s).  64-wide tile: deep chunks, 4x fewer barriers than KC = 16 (25 -> 17 us at 16^3).
+    if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
+    if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 64, 1, 1, 64>(a, s);
     return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 128, 1, 1, 32>(a, s);   // few voxels: deep K chunks (the K loop is latency-bound)
   }
   if (a.M <= 32) {
