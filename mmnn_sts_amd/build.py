@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         if verbose:
             print(f"[mmnn_sts_amd.build] compiling {len(jobs)} file(s) for {ARCH}", flush=True)
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as ex:
             for warn in ex.map(run, jobs):
                 if warn and verbose:
                     sys.stderr.write(warn)

@@ -1,0 +1,6 @@
+// conv1 data gradient: explicit instantiation of the tile dispatch (see fprop_dispatch.hpp)
+#include "fprop_dispatch.hpp"
+
+namespace mmnn {
+template int dispatch<1, PRO_GRAD, EPI_MASK_ACCUM>(const FpropArgs&, hipStream_t);
+}  // namespace mmnn

@@ -1,0 +1,6 @@
+// conv2 data gradient: explicit instantiation of the tile dispatch (see fprop_dispatch.hpp)
+#include "fprop_dispatch.hpp"
+
+namespace mmnn {
+template int dispatch<27, PRO_GRAD, EPI_MASK_STORE>(const FpropArgs&, hipStream_t);
+}  // namespace mmnn
