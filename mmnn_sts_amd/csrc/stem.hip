@@ -1,5 +1,7 @@
 // Stem kernels: conv0 (7x7x7, stride 2) forward on fp32 MFMA, BN+ReLU+max-pool forward/backward, conv0 weight
 // gradient on fp32 MFMA.  Reference: models/densenet.py:199-202 and their autograd adjoints (main.py:469).
+#include <stdlib.h>
+
 #include "stem.hpp"
 
 namespace mmnn {
@@ -228,10 +230,94 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
   }
 }
 
+// LDS-tiled version: one block = (n, c, 4 x 4 pooled rows, full width).  The 9 x 9 conv-output rows those windows cover are
+// staged once as y = ReLU(a*x + b) (positions outside the tensor as -inf, so they never win), then every pooled voxel scans its
+// 27 taps from LDS in the same (kd, kh, kw) order and with the same strict '>' as the direct kernel above: 1.27 global reads per
+// input element instead of 3.4.
+constexpr int PF_TD = 4, PF_TH = 4, PF_ROWS = 2 * PF_TH + 1, PF_PLANES = 2 * PF_TD + 1;
+
+__global__ void __launch_bounds__(256) stem_pool_tiled_kernel(const StemPoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pf_smem[];
+  __shared__ float red[2][4];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Vi = a.Di * a.Hi * a.Wi, Vo = a.Do * a.Ho * a.Wo;
+  const int nh = (a.Ho + PF_TH - 1) / PF_TH;
+  const int pd0 = (blockIdx.x / nh) * PF_TD, ph0 = (blockIdx.x % nh) * PF_TH;
+  const int RS = a.Wi + 2;                       // column 0: w = -1, column Wi + 1: w = Wi
+  float ca, cb, mu, rs;
+  bn_fwd_coef(a.bn, c, ca, cb, mu, rs);
+  const float* xc = a.x + ((long)n * a.C + c) * Vi;
+  const float NEG = -INFINITY;
+  for (int r = threadIdx.x; r < PF_PLANES * PF_ROWS; r += 256) { pf_smem[r * RS] = NEG; pf_smem[r * RS + a.Wi + 1] = NEG; }
+  if ((a.Wi & 3) == 0 && (((uintptr_t)xc & 15) == 0)) {
+    const int wq = a.Wi / 4, items = PF_PLANES * PF_ROWS * wq;
+    for (int it = threadIdx.x; it < items; it += 256) {
+      const int q = it % wq, row = it / wq;
+      const int d = 2 * pd0 - 1 + row / PF_ROWS, h = 2 * ph0 - 1 + row % PF_ROWS;
+      const bool ok = (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xc + (ok ? ((long)d * a.Hi + h) * a.Wi + 4 * q : 0));   // unconditional load
+      float* dst = pf_smem + row * RS + 1 + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = ok ? fmaxf(fmaf(ca, x[e], cb), 0.f) : NEG;
+    }
+  } else {
+    const int items = PF_PLANES * PF_ROWS * a.Wi;
+    for (int it = threadIdx.x; it < items; it += 256) {
+      const int w = it % a.Wi, row = it / a.Wi;
+      const int d = 2 * pd0 - 1 + row / PF_ROWS, h = 2 * ph0 - 1 + row % PF_ROWS;
+      const bool ok = (unsigned)d < (unsigned)a.Di && (unsigned)h < (unsigned)a.Hi;
+      const float x = xc[ok ? ((long)d * a.Hi + h) * a.Wi + w : 0];
+      pf_smem[row * RS + 1 + w] = ok ? fmaxf(fmaf(ca, x, cb), 0.f) : NEG;
+    }
+  }
+  __syncthreads();
+  float s0 = 0.f, s1 = 0.f;
+  const int nout = PF_TD * PF_TH * a.Wo;
+  for (int i = threadIdx.x; i < nout; i += 256) {
+    const int wo = i % a.Wo, hl = (i / a.Wo) % PF_TH, dl = i / (a.Wo * PF_TH);
+    const int d_o = pd0 + dl, ho = ph0 + hl;
+    if (d_o >= a.Do || ho >= a.Ho) continue;
+    const float* base = pf_smem + ((2 * dl) * PF_ROWS + 2 * hl) * RS + 2 * wo;   // tap (0,0,0) = (2d-1, 2h-1, 2w-1) -> column 2w
+    float best = NEG;
+    int bi = 0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float v = base[(kd * PF_ROWS + kh) * RS + kw];
+          if (v > best) { best = v; bi = kd * 9 + kh * 3 + kw; }
+        }
+    const long p = ((long)d_o * a.Ho + ho) * a.Wo + wo;
+    a.out[(long)n * a.out_ns + (long)c * Vo + p] = best;
+    a.idx[((long)n * a.C + c) * Vo + p] = (unsigned char)bi;
+    s0 += best; s1 += best * best;
+  }
+  if (a.st_out.sum) {
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int rep = blockIdx.x & (NREP - 1);
+      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + c, (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + c, (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+  }
+}
+
 int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "stem pool: bad extent");
   MMNN_REQUIRE(a.Do == (a.Di - 1) / 2 + 1 && a.Ho == (a.Hi - 1) / 2 + 1 && a.Wo == (a.Wi - 1) / 2 + 1, "stem pool: output extent mismatch");
   const int Vo = a.Do * a.Ho * a.Wo;
+  const size_t smem = sizeof(float) * PF_PLANES * PF_ROWS * (size_t)(a.Wi + 2);
+  static const bool tiled = [] { const char* e = getenv("MMNN_POOL_TILED"); return !(e && e[0] == '0'); }();   // =0: direct kernel (debugging)
+  if (tiled && smem <= 64 * 1024) {   // default dynamic-LDS limit; wider rows (W > 200) take the direct kernel
+    MMNN_LAUNCH(stem_pool_tiled_kernel, dim3(cdiv(a.Do, PF_TD) * cdiv(a.Ho, PF_TH), a.C, a.N), dim3(256), smem, stream, a);
+    MMNN_HIP(hipGetLastError());
+    return 0;
+  }
   MMNN_LAUNCH(stem_pool_kernel, dim3(cdiv(Vo, 256), a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
