@@ -146,6 +146,7 @@ def train_survival(model, train_ds, val_ds, args, device, rank, world):
                         f"train C {np.nanmean(tr_c):.3f} val selection loss {sel:.4f} val C {np.nanmean(val_c):.3f}")
             if sel < best:
                 best = sel
+                os.makedirs(args.output_path, exist_ok=True)
                 torch.save(model.state_dict(), os.path.join(args.output_path, 'best_surv_model.pth'))
         if args.blend and (epoch + 1) % args.blend_update_interval == 0:
             blender.updateWeights(cp, ce, cd, yp, ye, yd)
