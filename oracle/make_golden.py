@@ -8,7 +8,9 @@ oracle/synth.py formula, so only expected outputs are stored).  Dropout probabil
 streams cannot be matched bit-wise; everything else is the reference's arithmetic as published.
 
 Fixture families: G1 mlp, G2 densenet, G3 fusion train step, G4 fusion eval, G5 gradcam,
-G6 blender update sequence + Cox known answers, G7 tiny densenet.
+G6 blender update sequence + Cox known answers (+ fractional durations), G7 tiny densenet, G8 unimodal (BASELINE config 2)
+training step, G9 classification path of the blender / pos-weighted BCE, G10 r3d_18.  G3 / G5 / G8 also exist at the BASELINE
+extents (128^3, Grad-CAM 256^3): `--only g3big,g5big,g8` (minutes of CPU time, kept out of the default set).
 """
 import argparse
 import os
@@ -169,8 +171,8 @@ def build_fusion(blend: bool):
     return mm
 
 
-def g3_g4_fusion(out):
-    for s in (32, 64):
+def g3_g4_fusion(out, sizes=(32, 64)):
+    for s in sizes:
         res = {}
         for blend in (True, False):
             tag = "blend" if blend else "plain"
@@ -202,7 +204,7 @@ def g3_g4_fusion(out):
                       "image_model.model.backbone.denseblock1.denselayer1.layers.norm1.weight",
                       "image_model.model.backbone.denseblock4.denselayer16.layers.conv2.weight"):
                 p = dict(mm.named_parameters())[k]
-                if p.grad is not None:
+                if p.grad is not None and (s < 128 or p.grad.numel() <= 4096):
                     res[f"{tag}/grad/{k}"] = p.grad.numpy()
             if s == 32:
                 p = dict(mm.named_parameters())["image_model.model.backbone.conv0.weight"]
@@ -216,8 +218,7 @@ def g3_g4_fusion(out):
         np.savez_compressed(os.path.join(out, f"g3_fusion_s{s}.npz"), **res)
 
 
-def g5_gradcam(out):
-    s = 64
+def g5_gradcam(out, s=64):
     mm = build_fusion(False)
     mm.eval()
     cam = MultiModalGradCAM(mm)
@@ -232,6 +233,34 @@ def g5_gradcam(out):
     res["act_after"] = cam.features.detach().numpy()      # activations after the cumulative in-place weighting
     res["last_grads"] = cam.grads.detach().numpy()         # gradient of class C-1 at the hooked conv
     np.savez_compressed(os.path.join(out, f"g5_gradcam_s{s}.npz"), **res)
+
+
+def g8_unimodal(out, sizes=(64, 128)):
+    """BASELINE config 2 (`--images --survival`, modality t1): DenseNet121(in=1) full forward incl. class_layers ->
+    surv_criterion(CoxPH) -> backward  (reference main.py:451,460,466,469)."""
+    for s in sizes:
+        m = DenseNet121(spatial_dims=3, in_channels=1, out_channels=2, feature_channels=12, dropout_prob=0.2)
+        load_synth(m, "densenet.")
+        zero_dropout(m)
+        m.train()
+        n = 2
+        x = image_in(n, 1, s)
+        ev, du = labels(n)
+        y = m(x)
+        loss = surv_criterion(CoxPH, y, ev, du, "cpu")
+        loss.backward()
+        res = {"out": y.detach().numpy(), "loss": np.array([loss.item()], dtype=np.float64)}
+        res.update(grad_probes(m))
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+        res["grad_global_l2"] = np.array([gn])
+        for k in ("class_layers.out.weight", "class_layers.out.bias", "features.feature_layer.weight", "backbone.norm5.weight",
+                  "backbone.norm0.weight", "backbone.denseblock1.denselayer1.layers.norm1.weight"):
+            res[f"grad/{k}"] = dict(m.named_parameters())[k].grad.numpy()
+        res.update(bn_running(m))
+        m.eval()
+        with torch.no_grad():
+            res["eval_out"] = m(x).numpy()
+        np.savez_compressed(os.path.join(out, f"g8_unimodal_in1_s{s}.npz"), **res)
 
 
 def g6_blender(out):
@@ -277,9 +306,12 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    jobs = {"g1": g1_mlp, "g2": g2_densenet, "g3": g3_g4_fusion, "g5": g5_gradcam, "g6": g6_blender, "g7": g7_tiny}
+    jobs = {"g1": g1_mlp, "g2": g2_densenet, "g3": g3_g4_fusion, "g5": g5_gradcam, "g6": g6_blender, "g7": g7_tiny,
+            "g8": g8_unimodal}
+    big = {"g3big": lambda o: g3_g4_fusion(o, sizes=(128,)), "g5big": lambda o: [g5_gradcam(o, 128), g5_gradcam(o, 256)]}
+    jobs.update(big)
     for k, fn in jobs.items():
-        if a.only and k not in a.only.split(","):
+        if (a.only and k not in a.only.split(",")) or (not a.only and k in big):
             continue
         print("generating", k, flush=True)
         fn(a.out)

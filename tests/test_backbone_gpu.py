@@ -84,6 +84,41 @@ def test_backbone_forward_backward(in_ch, blocks, dhw, n):
     print("forward rel errors", errs, "worst gradient (err/tol, name)", worst)
 
 
+# Tile-instantiation matrix.  Tile shapes are picked from the extent (csrc/fprop_dispatch.hpp: `dispatch`, csrc/wgrad.hip:
+# `wg3_tile`, `wg1_wc`), so every branch needs an extent of its own.  Block-1 extents of the cases (block 2 = half of it):
+#   20^3 (N=4)    W > 16: wave-specialised conv2 forward <27,..,2,4,32,true>, KC=2 conv2 data-grad <27,PRO_GRAD,..,1,4,32>,
+#                 wgrad3<1,2,32>; 252 voxel tiles -> 128-wide 1x1x1 tile for conv1 forward / data-grad; block 2: W = 10 tiles
+#   6x10x17       ragged W just above the 16 boundary, odd rows (no 16-byte staging: scalar path of the W > 16 tiles)
+#   4x6x33        W = 33: one full 32-wide tile + a 1-voxel remainder tile in every row
+#   12x12x40      64-wide 1x1x1 tile (blocks_a < 192 <= blocks_b) incl. the PRO_NONE transition conv at 20x6x6
+# The BASELINE extents themselves (32^3 .. 4^3 at N = 2) run in test_baseline_config3_backbone_128.
+MATRIX = [
+    (2, (2, 2), (80, 80, 80), 4),
+    (2, (2, 2), (24, 40, 66), 2),
+    (1, (2, 2), (16, 24, 130), 2),
+    (2, (3, 2), (48, 48, 160), 2),
+]
+
+
+@pytest.mark.parametrize("in_ch,blocks,dhw,n", MATRIX)
+def test_backbone_tile_matrix(in_ch, blocks, dhw, n):
+    errs, worst = _run_case(in_ch, blocks, dhw, n)
+    print("forward rel errors", errs, "worst gradient (err/tol, name)", worst)
+
+
+def test_baseline_config3_backbone_128():
+    """The backbone of BASELINE configs[2] at its own size (2 x 2 x 128^3): every intermediate, the running statistics and all
+    364 backbone gradients against the fp64 oracle -- this is the extent whose W > 16 tiles the benchmark dispatches to."""
+    errs, worst = _run_case(2, (6, 12, 24, 16), (128, 128, 128), 2)
+    print("forward rel errors", errs, "worst gradient (err/tol, name)", worst)
+
+
+def test_baseline_config2_backbone_128():
+    """BASELINE configs[1]: single-channel (t1) volumes, 2 x 1 x 128^3."""
+    errs, worst = _run_case(1, (6, 12, 24, 16), (128, 128, 128), 2)
+    print("forward rel errors", errs, "worst gradient (err/tol, name)", worst)
+
+
 def test_backbone_minimum_extent():
     """32^3 is the smallest legal input: every block must run (1x1x1 voxels in block 4)."""
     _run_case(2, (6, 12, 24, 16), (32, 32, 32), 2, full=False)

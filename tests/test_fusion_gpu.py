@@ -130,15 +130,15 @@ def test_mlp_golden(n):
 
 
 @pytest.mark.parametrize("blend", [True, False])
-def test_fusion_train_step_golden(blend):
-    """One training step at 64^3 against the numbers recorded from the reference's own classes (fp32 CPU).  Outputs / losses
-    at the north-star bar (1e-4).  Gradients against this golden only loosely: the reference's fp32 ReLU branches at
-    near-zero pre-activations differ from any other fp32 evaluation; the strict gradient check is
-    test_fusion_gradients_fp64 below."""
+@pytest.mark.parametrize("s", [64, 128])
+def test_baseline_config3_fusion_train_step_golden(blend, s):
+    """BASELINE configs[2] (`--images --preop --survival [--blend]`): one training step at 64^3 and at the BASELINE extent
+    2 x 2 x 128^3 against the numbers recorded from the reference's own classes (fp32 CPU).  Outputs / losses at the north-star
+    bar (1e-4).  Gradients against this golden only loosely: the reference's fp32 ReLU branches at near-zero pre-activations
+    differ from any other fp32 evaluation; the strict gradient check is test_baseline_config3_fusion_gradients_fp64."""
     from mmnn_sts_amd.losses.GradientBlender import GradientBlender
     from mmnn_sts_amd.losses.losses import CoxPH
     from mmnn_sts_amd.utils.utils import surv_criterion
-    s = 64
     g = load_golden(f"g3_fusion_s{s}.npz")
     tag = "blend" if blend else "plain"
     mm = _zero_dropout(_fusion(blend))
@@ -178,13 +178,60 @@ def test_fusion_train_step_golden(blend):
     assert rel_err(oe.cpu().numpy(), g[f"{tag}/eval_out"]) < 1e-4
 
 
-def test_fusion_gradients_fp64():
-    """Every parameter gradient of the blended training step against the fp64 oracle taking the device's ReLU branches."""
+def _device_relu_masks(bb, x, cfg):
+    """ReLU branch decisions of the last training forward of backbone module `bb` on input `x`, keyed like the oracle's taps."""
+    from mmnn_sts_amd import _lib
+    ent = bb._plans[(tuple(x.shape), x.device.index)]
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n, s = x.shape[0], x.shape[2]
+
+    def fetch(kind, b, l, shape):
+        m = torch.empty(shape, dtype=torch.uint8, device=DEV)
+        _lib.check(L.mmnn_densenet_relu_mask(ent["plan"], bb._flat.data_ptr(), ent["ws"].data_ptr(), kind, b, l, m.data_ptr(), st), "relu_mask")
+        return m.cpu()
+
+    masks = {"relu0": fetch(0, 0, 0, (n, cfg.init_features, s // 2, s // 2, s // 2))}
+    dims, c = s // 4, cfg.init_features
+    mid = cfg.bn_size * cfg.growth_rate
+    for b, nl in enumerate(cfg.block_config):
+        for l in range(nl):
+            masks[f"b{b + 1}l{l + 1}r1"] = fetch(1, b, l, (n, c, dims, dims, dims))
+            masks[f"b{b + 1}l{l + 1}r2"] = fetch(2, b, l, (n, mid, dims, dims, dims))
+            c += cfg.growth_rate
+        if b != len(cfg.block_config) - 1:
+            masks[f"t{b + 1}"] = fetch(3, b, 0, (n, c, dims, dims, dims))
+            c //= 2
+            dims //= 2
+    return masks
+
+
+def _compare_all_grads(named_params, sd):
+    gl2 = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sd.values() if v.is_floating_point() and v.grad is not None)))
+    bad, seen = [], 0
+    for k, p in named_params:
+        ref = sd[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        seen += 1
+        err = float((p.grad.double().cpu() - ref).norm())
+        tol = 1e-3 * float(ref.norm()) + 1e-5 * gl2
+        if err > tol:
+            bad.append((k, err, float(ref.norm())))
+    assert not bad, (len(bad), gl2, bad[:8])
+    return seen
+
+
+@pytest.mark.parametrize("s", [64, 128])
+def test_baseline_config3_fusion_gradients_fp64(s):
+    """BASELINE configs[2] with --blend: every one of the 394 parameter gradients of the blended training step (64^3 and the
+    BASELINE extent 2 x 2 x 128^3) against the fp64 oracle taking the device's ReLU branches."""
     from mmnn_sts_amd import _lib
     from mmnn_sts_amd.losses.GradientBlender import GradientBlender
     from mmnn_sts_amd.losses.losses import CoxPH
     from mmnn_sts_amd.utils.utils import surv_criterion
-    s, n = 64, 2
+    n = 2
     mm = _zero_dropout(_fusion(True))
     mm.train()
     x = {"image": image_in(n, 2, s).to(DEV), "clinical": clin_in(n).to(DEV)}
@@ -193,29 +240,8 @@ def test_fusion_gradients_fp64():
     gb = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion)
     loss, _ = gb.computeLoss(out, ev.to(DEV), du.to(DEV))
     loss.backward()
-    # device ReLU branches of the backbone
-    bb = mm.image_model.model.backbone
-    ent = bb._plans[(tuple(x["image"].shape), x["image"].device.index)]
-    L = _lib.lib()
-    st = torch.cuda.current_stream().cuda_stream
     cfg = R.DenseNetCfg()
-
-    def fetch(kind, b, l, shape):
-        m = torch.empty(shape, dtype=torch.uint8, device=DEV)
-        _lib.check(L.mmnn_densenet_relu_mask(ent["plan"], bb._flat.data_ptr(), ent["ws"].data_ptr(), kind, b, l, m.data_ptr(), st), "relu_mask")
-        return m.cpu()
-
-    masks = {"relu0": fetch(0, 0, 0, (n, 64, s // 2, s // 2, s // 2))}
-    dims, c = s // 4, 64
-    for b, nl in enumerate(cfg.block_config):
-        for l in range(nl):
-            masks[f"b{b + 1}l{l + 1}r1"] = fetch(1, b, l, (n, c, dims, dims, dims))
-            masks[f"b{b + 1}l{l + 1}r2"] = fetch(2, b, l, (n, 128, dims, dims, dims))
-            c += 32
-        if b != 3:
-            masks[f"t{b + 1}"] = fetch(3, b, 0, (n, c, dims, dims, dims))
-            c //= 2
-            dims //= 2
+    masks = _device_relu_masks(mm.image_model.model.backbone, x["image"], cfg)
     sch = R.multimodal_schema(cfg, N_CLIN, 2, 12)
     sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in synth_sd(sch, "fusion.").items()}
     o64 = R.multimodal_forward(sd, image_in(n, 2, s).double(), clin_in(n).double(), cfg, True, True, mlp_dropout=0.0, relu_masks=masks)
@@ -226,23 +252,14 @@ def test_fusion_gradients_fp64():
     l64.backward()
     assert rel_err(out.detach().cpu().numpy(), o64.detach().numpy()) < 1e-4
     assert abs(loss.item() - l64.item()) < 1e-4 * abs(l64.item())
-    gl2 = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sd.values() if v.is_floating_point() and v.grad is not None)))
-    bad = []
-    for k, p in mm.named_parameters():
-        ref = sd[k].grad
-        if ref is None:
-            assert p.grad is None, k
-            continue
-        err = float((p.grad.double().cpu() - ref).norm())
-        tol = 1e-3 * float(ref.norm()) + 1e-5 * gl2
-        if err > tol:
-            bad.append((k, err, float(ref.norm())))
-    assert not bad, (len(bad), gl2, bad[:8])
+    assert _compare_all_grads(mm.named_parameters(), sd) == 394   # 398 tensors - the 4 that never get a gradient
 
 
-def test_gradcam_golden():
-    g = load_golden("g5_gradcam_s64.npz")
-    s = 64
+@pytest.mark.parametrize("s", [64, 128, 256])
+def test_baseline_config5_gradcam_golden(s):
+    """BASELINE configs[4] (`--inference --images --preop --survival`): Grad-CAM on one patient, up to the BASELINE extent
+    1 x 2 x 256^3, against the reference's MultiModalGradCAM (risk scores, both attention maps, hooked activations / gradients)."""
+    g = load_golden(f"g5_gradcam_s{s}.npz")
     mm = _fusion(False, dropout=0.2)
     mm.eval()
     cam = mm.add_gradcam("unused")
@@ -258,8 +275,54 @@ def test_gradcam_golden():
     np.testing.assert_allclose(cam.grads.cpu().numpy(), g["last_grads"], rtol=2e-3, atol=1e-6 * np.abs(g["last_grads"]).max())
 
 
+@pytest.mark.parametrize("s", [64, 128])
+def test_baseline_config2_unimodal_train_step(s):
+    """BASELINE configs[1] (`--images --survival`, modality t1): DenseNet121(in=1) full forward incl. class_layers ->
+    surv_criterion(CoxPH) -> backward (reference main.py:451,460,466,469) at 64^3 and at the BASELINE extent 2 x 1 x 128^3:
+    risk scores / loss / running statistics / eval forward against the reference-generated golden at 1e-4, and every one of the
+    368 gradients against the fp64 oracle taking the device's ReLU branches."""
+    from mmnn_sts_amd.losses.losses import CoxPH
+    from mmnn_sts_amd.models.densenet import DenseNet121
+    from mmnn_sts_amd.utils.utils import surv_criterion
+    g = load_golden(f"g8_unimodal_in1_s{s}.npz")
+    cfg = R.DenseNetCfg(in_channels=1)
+    sch = R.densenet_schema(cfg)
+    m = DenseNet121(spatial_dims=3, in_channels=1, out_channels=2, feature_channels=12, dropout_prob=0.0)
+    _load(m, sch, "densenet.").to(DEV)
+    m.train()
+    n = 2
+    x = image_in(n, 1, s).to(DEV)
+    ev, du = labels(n)
+    y = m(x)
+    loss = surv_criterion(CoxPH, y, ev.to(DEV), du.to(DEV), DEV)
+    loss.backward()
+    assert rel_err(y.detach().cpu().numpy(), g["out"]) < 1e-4
+    assert abs(loss.item() - g["loss"][0]) < 1e-4 * abs(g["loss"][0])
+    params = dict(m.named_parameters())
+    mine = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())))
+    assert abs(mine - float(g["grad_global_l2"][0])) < 0.05 * float(g["grad_global_l2"][0])
+    for k in ("class_layers.out.weight", "class_layers.out.bias"):     # downstream of every ReLU: exact to fp32 round-off
+        np.testing.assert_allclose(params[k].grad.cpu().numpy(), g[f"grad/{k}"], rtol=2e-3, atol=1e-5 * np.abs(g[f"grad/{k}"]).max() + 1e-7)
+    sd_dev = m.state_dict()
+    for k, v in zip(g["running_names"], g["running_chk"]):
+        t = sd_dev[str(k)].double()
+        np.testing.assert_allclose([t.sum().item(), t.abs().sum().item()], v, rtol=1e-4, atol=1e-5)
+    # strict: fp64 oracle with the device's ReLU branches
+    masks = _device_relu_masks(m.backbone, x, cfg)
+    sd = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in synth_sd(sch, "densenet.").items()}
+    y64 = R.densenet_forward(sd, image_in(n, 1, s).double(), cfg, True, relu_masks=masks)
+    l64 = R.surv_criterion(R.CoxPH, y64, ev, du)
+    l64.backward()
+    assert rel_err(y.detach().cpu().numpy(), y64.detach().numpy()) < 1e-4
+    assert abs(loss.item() - l64.item()) < 1e-4 * abs(l64.item())
+    assert _compare_all_grads(m.named_parameters(), sd) == 368
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x).cpu().numpy(), g["eval_out"]) < 1e-4
+
+
 def test_unimodal_densenet_forward_golden():
-    """BASELINE config 2: DenseNet121(in=1) backbone -> features -> class_layers, train and eval."""
+    """DenseNet121(in=2) backbone -> features -> class_layers, train and eval, against G2 at 64^3."""
     from mmnn_sts_amd.models.densenet import DenseNet121
     g = load_golden("g2_densenet_in2_s64.npz")
     cfg = R.DenseNetCfg(in_channels=2)
