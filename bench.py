@@ -8,14 +8,21 @@ patients (2 x 2 x 128^3 fp32 volumes + 2 x 32 tabular), GradientBlender-weighted
 gradients over the ranks (N > 1), fused SGD-Nesterov step + OneCycleLR step, zero_grad.  Dropout p = 0.2 active.  Every
 rank owns its own patients (weak scaling); value = volumes processed by ALL ranks / max-over-ranks wall time.
 
-Extra legs (rank 0, N = 1 only): `roofline` -- live HIP-event timing of the dominant kernel (3x3x3 dense-layer convolution
-forward in dense block 1) against the fp32 MFMA peak; `cpu_baseline` -- the CPU restatement (oracle/, plain torch.nn.functional,
-parity-checked against the reference) timed on the host cores for a bounded sample of the same workload.
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (torch.distributed.run as a child process, before
+anything here touches the GPU) and relays rank 0's JSON line; every rank asserts that the process group really has N members.
+
+Extra legs (rank 0, N = 1 only): `roofline` -- after the timed region, a few more (untimed) steps with every convolution launch
+bracketed by HIP events on its own launch stream and the backward serialised on one stream (un-overlapped durations); the
+kernel class with the largest total time is reported against the fp32 MFMA peak, the other classes beside it;
+`cpu_baseline` -- the CPU restatement (oracle/, plain torch.nn.functional, parity-checked against the reference) timed on
+the host cores for a bounded sample of the same workload.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,8 +54,8 @@ def synth_batch(device, rank, n=2, s=128):
     return {"image": image, "clinical": clinical}, events, durations
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_traffic.json: separate
+def measured_traffic(key=None):
+    """HBM bytes per launch of a kernel class from the committed PMC passes (profiles/rNN_traffic.json: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied); None when
     no such measurement is committed.  Counters cannot be read from inside the timed run."""
     import glob
@@ -56,9 +63,85 @@ def measured_traffic():
     if not files:
         return None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        d = json.load(open(files[-1]))
+        if key is not None and isinstance(d.get("kernels"), dict):
+            e = d["kernels"].get(key)
+            return float(e["hbm_bytes_per_launch"]) if e else None
+        return float(d["hbm_bytes_per_launch"]) if key in (None, "conv2_fwd.b1") else None
     except Exception:
         return None
+
+
+KCLASS = {1: "conv2_fwd", 2: "conv2_dgrad", 3: "conv2_wgrad", 4: "conv1_fwd", 5: "conv1_dgrad", 6: "conv1_wgrad", 7: "stem_conv",
+          8: "stem_wgrad"}
+KDESC = {1: "fprop_kernel<27,PRO_BNRELU,EPI_STORE_STATS> conv2 3x3x3 128->32 forward",
+         2: "fprop_kernel<27,PRO_GRAD,EPI_MASK_STORE> conv2 3x3x3 data gradient 32->128",
+         3: "wgrad3_kernel conv2 3x3x3 weight gradient",
+         4: "fprop_kernel<1,PRO_BNRELU,EPI_STORE_STATS> conv1 1x1x1 C->128 forward",
+         5: "fprop_kernel<1,PRO_GRAD,EPI_MASK_ACCUM> conv1 1x1x1 data gradient 128->C",
+         6: "wgrad1_kernel conv1 1x1x1 weight gradient",
+         7: "stem_conv_kernel conv0 7x7x7 stride 2 forward", 8: "stem_wgrad_kernel conv0 weight gradient"}
+
+
+def class_flops(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32, mid=128, init=64):
+    """Algorithmic FLOPs of ALL launches of one kernel class in one dense block during one step (2 x MACs)."""
+    if kind in (7, 8):
+        return 2.0 * n * (size // 2) ** 3 * init * in_ch * 343
+    v = (size // 4) ** 3
+    c = init
+    for b in range(block):
+        c = (c + blocks[b] * growth) // 2
+        v //= 8
+    if kind in (1, 2, 3):
+        return blocks[block] * 2.0 * n * v * growth * mid * 27
+    return sum(2.0 * n * v * mid * (c + growth * l) for l in range(blocks[block]))
+
+
+def kernel_roofline(L, plan, step, n, size, steps=4):
+    """Per-class device time of every convolution launch: events on the launch stream, backward on ONE stream so that the
+    durations are not inflated by kernels overlapping on the side streams.  Runs `steps` extra steps after the timed region."""
+    _lib_check = __import__("mmnn_sts_amd._lib", fromlist=["check"]).check
+    _lib_check(L.mmnn_densenet_set_option(plan, b"single_stream", 1), "set_option")
+    step()                                                     # settle into the serialised schedule
+    torch.cuda.synchronize()
+    _lib_check(L.mmnn_densenet_set_timer(plan, -1, -1), "set_timer")
+    rows = {}
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()
+        for kind in KCLASS:
+            for b in range(4 if kind < 7 else 1):
+                ms, cnt = ctypes.c_double(), ctypes.c_int64()
+                _lib_check(L.mmnn_densenet_read_timer_class(plan, kind, b, ctypes.byref(ms), ctypes.byref(cnt)), "read_timer")
+                rows[(kind, b)] = (ms.value, cnt.value)     # accumulated since set_timer
+    L.mmnn_densenet_set_timer(plan, 0, -1)
+    L.mmnn_densenet_set_option(plan, b"single_stream", 0)
+    out = []
+    for (kind, b), (ms, cnt) in rows.items():
+        if cnt == 0:
+            continue
+        flop = class_flops(kind, b, n, size) * steps
+        tf = flop / (ms * 1e-3) / 1e12
+        name = KCLASS[kind] + (f".b{b + 1}" if kind < 7 else "")
+        out.append({"class": name, "kernel": KDESC[kind] + (f", dense block {b + 1}" if kind < 7 else ""), "launches": int(cnt),
+                    "ms_per_step": ms / steps, "avg_us": ms / cnt * 1e3, "flop_per_launch": flop / cnt, "achieved": tf,
+                    "frac": tf / PEAK_FP32_TFLOPS})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torch.distributed.run, relay its
+    output and exit code.  Nothing in this process has touched the GPU yet (no HIP call, no torch.cuda.is_available())."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores() -> int:
@@ -130,7 +213,10 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--micro-batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
 
     from mmnn_sts_amd import _lib, distributed as D
     from mmnn_sts_amd.losses.GradientBlender import GradientBlender
@@ -139,11 +225,21 @@ def main():
     from mmnn_sts_amd.utils.utils import surv_criterion
 
     rank, world, local = D.init_from_env(os.environ.get("MMNN_DIST_BACKEND", "nccl"))   # "nccl" = RCCL; gloo only for rehearsals
-    local = local % max(1, torch.cuda.device_count())
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: every rank must be launched (torch.distributed.run or plain `bench.py --gpus N`)")
+    ndev = torch.cuda.device_count()
+    if ndev < world and os.environ.get("MMNN_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {a.gpus} but only {ndev} device(s) visible (ranks may share a device only in gloo rehearsals)")
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ranks_seen = 1
+    if world > 1:
+        assert torch.distributed.get_world_size() == a.gpus
+        seen = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(seen)
+        ranks_seen = int(seen.item())
+        assert ranks_seen == a.gpus, f"{ranks_seen} ranks answered the all-reduce, expected {a.gpus}"
     model = build_model(dev)
     D.broadcast_parameters(model)
     model.train()
@@ -177,9 +273,7 @@ def main():
     bb = model.image_model.model.backbone
     plan = next(iter(bb._plans.values()))["plan"]
     L = _lib.lib()
-    timed_kernel = rank == 0 and world == 1
-    if timed_kernel:
-        _lib.check(L.mmnn_densenet_set_timer(plan, 1, 0), "set_timer")    # conv2 (3x3x3) forward, dense block 1
+    timed_kernel = rank == 0 and world == 1 and not a.no_roofline
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -199,7 +293,7 @@ def main():
         res = {
             "metric": "training volumes/sec/GPU (128^3 T1+T2+preop, batch 2) at 1/2/4/8 MI355X",
             "value": value, "unit": "volumes/s (whole job; 1 volume = 1 patient = stacked T1+T2 2x128^3 + 32 tabular)",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "init_steps": init_steps, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup, "init_steps": init_steps, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "per_gpu": value / world,
             "config": {"workload": "configs[2] --images --preop --survival --blend: MultiModalModel(DenseNet121-3D(in=2), MLP(32), "
@@ -209,17 +303,15 @@ def main():
             "step_fp32_frac_of_peak": value / world * GFLOP_PER_VOLUME / 1e3 / PEAK_FP32_TFLOPS if a.size == 128 else None,
         }
         if timed_kernel:
-            ms, cnt = ctypes.c_double(), ctypes.c_int64()
-            _lib.check(L.mmnn_densenet_read_timer(plan, ctypes.byref(ms), ctypes.byref(cnt)), "read_timer")
-            L.mmnn_densenet_set_timer(plan, 0, -1)
-            v1 = (a.size // 4) ** 3
-            flop = 2.0 * a.micro_batch * v1 * 32 * 128 * 27            # one launch: N*V voxels x 32 out x (128 in x 27 taps) MACs x 2
-            avg_s = ms.value / max(cnt.value, 1) * 1e-3
-            ach = flop / avg_s / 1e12 if avg_s > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "fprop_kernel<27,...> conv2 3x3x3 128->32 forward, dense block 1",
-                               "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                               "traffic": measured_traffic(), "launches_timed": int(cnt.value), "avg_us": avg_s * 1e6,
-                               "flop_per_launch": flop}
+            rows = kernel_roofline(L, plan, step, a.micro_batch, a.size)
+            top = rows[0]
+            res["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "class": top["class"], "achieved": top["achieved"],
+                               "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"], "traffic": measured_traffic(top["class"]),
+                               "launches_timed": top["launches"], "avg_us": top["avg_us"], "flop_per_launch": top["flop_per_launch"],
+                               "ms_per_step": top["ms_per_step"], "step_frac": res["step_fp32_frac_of_peak"],
+                               "timing": "HIP events on the launch stream, 4 untimed steps after the timed region, backward on one stream",
+                               "conv_ms_per_step": sum(r["ms_per_step"] for r in rows),
+                               "classes": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"} for r in rows[:12]]}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.micro_batch, a.size)
         print(json.dumps(res), flush=True)

@@ -13,8 +13,12 @@
  *     1 = invalid argument / shape (-> ValueError), 2 = HIP runtime error (-> RuntimeError).  Never aborts.
  *   - the caller (PyTorch) owns every device buffer; the library never allocates, frees or retains device memory.
  *     Workspace sizes come from pure query functions.  All tensors are contiguous fp32, NCDHW.
- *   - re-entrant: no global mutable state besides the thread-local error text; a plan handle must not be used from
- *     two threads at once (autograd calls backward from another thread than forward, sequentially: fine).
+ *   - threading: the library keeps no mutable state of its own besides the thread-local error text and per-device
+ *     "kernel attribute already set" flags (idempotent; written with the value every writer would write).  A PLAN, however, is
+ *     a stateful object: it owns host-side job tables (one pinned staging buffer), two lazily created side streams and a pool
+ *     of events for its backward, and optional timers.  One plan must therefore not be used from two threads at once, and it
+ *     belongs to the device that was current when its first forward ran.  Sequential use from different threads is fine
+ *     (autograd calls backward from another thread than forward).  Different plans are independent of each other.
  */
 #ifndef MMNN_STS_H
 #define MMNN_STS_H
@@ -63,12 +67,17 @@ int mmnn_densenet_backward(void* plan, const float* params, const float* x, void
  * Used by the gradient parity tests (ReLU is not differentiable at 0: a reference must take the same branch). */
 int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, int32_t kind, int32_t block, int32_t layer,
                             uint8_t* out, void* stream);
-/* measurement: time every launch of one kernel class with HIP events recorded on the launch stream.
+/* measurement: time every launch of one kernel class (-1: of every class) with HIP events recorded on the launch stream.
  * kernel_class 0 none, 1 conv2 fwd, 2 conv2 dgrad, 3 conv2 wgrad, 4 conv1 fwd, 5 conv1 dgrad, 6 conv1 wgrad, 7 stem conv,
  * 8 stem wgrad; block >= 0 restricts to one dense block (0-based).  read_timer synchronises the recorded events and returns
- * the accumulated device time and launch count since set_timer. */
+ * the accumulated device time and launch count since set_timer (read_timer: all recorded classes and blocks together;
+ * read_timer_class: one class (0: all) of one dense block (< 0: all)). */
 int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
+int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches);
+/* plan options.  "single_stream" (0/1): run the whole backward on the caller's stream instead of overlapping the weight-gradient
+ * kernels on two side streams -- same results, un-overlapped kernel durations for profiling. */
+int mmnn_densenet_set_option(void* plan, const char* name, int64_t value);
 /* byte offset of a named workspace region (tests / GradCAM): "x","g","t1","conv0","st_x",... ; -1 if unknown */
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j);
 
@@ -126,11 +135,13 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
                          float* db, int32_t accumulate, void* stream);
 
 /* ---- Cox partial likelihood summed over targets and blended over heads (losses/losses.py:6-9 -> pycox CoxPHLoss,
- * utils/utils.py:24-29, losses/GradientBlender.py:197-205).  preds [heads][n][c]; sort_key / weight [n][c] int64: pycox's
- * `durations` / `events` arguments (the reference passes events / durations there, in that order).  Stable descending sort.
+ * utils/utils.py:24-29, losses/GradientBlender.py:197-205).  preds [heads][n][c]; sort_key / weight [n][c] fp64: pycox's
+ * `durations` / `events` arguments (the reference passes events / durations there, in that order; its datasets build them as
+ * int64 or float32 tensors, data/ImageDatasets.py:462 -- both are exact in fp64, fractional durations included).  Stable
+ * descending sort.
  * Writes loss = sum_h head_weights[h] * head_losses[h] (head_weights NULL: all 1), head_losses[h] = sum_c cox(h, c), and
  * grad_preds = d loss / d preds.  scratch: 4 * n floats. */
-int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const int64_t* sort_key, const int64_t* weight,
+int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
                         const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream);
 
 /* ---- optimizer step over a flat buffer: torch.optim.SGD(momentum, nesterov, weight_decay) as main.py:410-413 uses it.

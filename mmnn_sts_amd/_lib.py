@@ -78,6 +78,8 @@ def lib():
         "mmnn_sgd_step": [V, V, V, c_int64, F, F, F, I, I, V],
         "mmnn_densenet_set_timer": [V, I, I],
         "mmnn_densenet_read_timer": [V, POINTER(ctypes.c_double), POINTER(c_int64)],
+        "mmnn_densenet_read_timer_class": [V, I, I, POINTER(ctypes.c_double), POINTER(c_int64)],
+        "mmnn_densenet_set_option": [V, c_char_p, c_int64],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -1,9 +1,10 @@
 """Build libmmnn_sts.so (hand-written HIP for gfx950) in-tree with hipcc.  `python -m mmnn_sts_amd.build`.
 
 No torch.utils.cpp_extension (it hipifies), no cmake: one object per .hip file, compiled in parallel, linked into
-mmnn_sts_amd/libmmnn_sts.so.  Objects are rebuilt only when a source or header is newer.
+mmnn_sts_amd/libmmnn_sts.so.  An object is rebuilt only when its source or a header it includes (transitively) is newer.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -20,23 +21,33 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    hs.append(os.path.join(os.path.dirname(HERE), "include", "mmnn_sts.h"))
-    return max(os.path.getmtime(h) for h in hs)
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps_mtime(path, seen=None):
+    """Newest modification time of `path` and of every project header it includes (transitively): a header edit rebuilds
+    only the translation units that see it (the big convolution TUs take minutes each)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return 0.0
+    seen.add(path)
+    t = os.path.getmtime(path)
+    for inc in _INC.findall(open(path).read()):
+        t = max(t, _deps_mtime(os.path.join(os.path.dirname(path), inc), seen))
+    return t
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    hdr = _newest_header()
     jobs = []
     objs = []
     for src in _sources():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
+        if force or not os.path.exists(o) or os.path.getmtime(o) < _deps_mtime(s):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
             jobs.append([hipcc, *FLAGS, *lang, "-c", s, "-o", o])
 

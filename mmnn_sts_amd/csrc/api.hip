@@ -72,11 +72,20 @@ int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block) {
 }
 
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches) {
+  return mmnn_densenet_read_timer_class(plan, 0, -1, total_ms, launches);
+}
+
+int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches) {
   MMNN_REQUIRE(plan, "read_timer: null plan");
   long n = 0;
-  int rc = plan_read_timer(*static_cast<Plan*>(plan), total_ms, &n);
+  int rc = plan_read_timer(*static_cast<Plan*>(plan), kernel_class, block, total_ms, &n);
   if (launches) *launches = n;
   return rc;
+}
+
+int mmnn_densenet_set_option(void* plan, const char* name, int64_t value) {
+  MMNN_REQUIRE(plan && name, "set_option: null argument");
+  return plan_set_option(*static_cast<Plan*>(plan), name, (long)value);
 }
 
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j) {

@@ -14,6 +14,9 @@
 namespace mmnn {
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+// cross-block K-split scratch of the plan's workspace: <= 512 blocks x (up to 4) 32x32 partial tiles, + per-tile counters
+constexpr size_t KZ_PART_BYTES = (size_t)512 * 4 * 1024 * sizeof(float);
+constexpr unsigned KZ_CNT_ENTRIES = 4096;
 
 namespace {
 struct Carver {
@@ -163,9 +166,8 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   // side stream, several layers behind the data-gradient chain, and must never make the chain wait for a buffer.
   for (int b = 0; b < nb; ++b) p.o_dz2[b] = cv.take((size_t)cfg.block_layers[b] * N * p.mid * p.Vb[b] * F);
   // cross-block K-split scratch: <= 256 blocks x one 32x32 (or 4 x 32x32) partial tile each, + per-tile counters
-  constexpr size_t KZ_PART = (size_t)512 * 4 * 1024 * sizeof(float), KZ_CNT = 4096;
-  p.o_kz_part = cv.take(KZ_PART);
-  p.o_kz_cnt = cv.take(KZ_CNT * sizeof(unsigned));
+  p.o_kz_part = cv.take(KZ_PART_BYTES);
+  p.o_kz_cnt = cv.take(KZ_CNT_ENTRIES * sizeof(unsigned));
   // job tables
   int nlayers = 0;
   for (int b = 0; b < nb; ++b) nlayers += cfg.block_layers[b];
@@ -203,6 +205,12 @@ static StatPtr statptr(char* ws, size_t o, int C, int off) {
   return s;
 }
 static float* fptr(char* ws, size_t o) { return reinterpret_cast<float*>(ws + o); }
+
+// capacities travel with the arguments: no process-global state
+static void set_kz(FpropArgs& a, const Plan& p, char* ws) {
+  a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+  a.kz_part_bytes = KZ_PART_BYTES; a.kz_cnt_entries = KZ_CNT_ENTRIES;
+}
 
 static BnFwd bnfwd(const Plan& p, StatPtr st, const float* params, float* run, long w, long b, long rm, long rv, double count, int training) {
   BnFwd f;
@@ -292,13 +300,15 @@ namespace {
 struct ScopedTimer {   // records a start/stop event pair around one launch when the plan's timer selects it
   Plan& p; hipStream_t s; bool on;
   ScopedTimer(Plan& p_, int kind, int block, hipStream_t s_) : p(p_), s(s_), on(false) {
-    if (p.timer_kind != kind || (p.timer_block >= 0 && p.timer_block != block)) return;
+    if (!((p.timer_mask >> kind) & 1u) || (p.timer_block >= 0 && p.timer_block != block)) return;
     if (p.timer_used + 2 > p.timer_ev.size()) {
-      if (p.timer_ev.size() >= 4096) return;   // read_timer() was not called for a long time: stop recording
+      if (p.timer_ev.size() >= 16384) return;   // read_timer() was not called for a long time: stop recording
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
       p.timer_ev.push_back(a); p.timer_ev.push_back(b);
+      p.timer_tag.push_back(0);
     }
+    p.timer_tag[p.timer_used / 2] = kind * MAX_BLOCKS + (block >= 0 && block < MAX_BLOCKS ? block : 0);
     on = hipEventRecord(p.timer_ev[p.timer_used], s) == hipSuccess;
   }
   ~ScopedTimer() {
@@ -310,22 +320,37 @@ struct ScopedTimer {   // records a start/stop event pair around one launch when
 }  // namespace
 
 int plan_set_timer(Plan& p, int kind, int block) {
-  MMNN_REQUIRE(kind >= T_NONE && kind <= T_STEM_WGRAD, "set_timer: unknown kernel class %d", kind);
-  p.timer_kind = kind; p.timer_block = block; p.timer_used = 0; p.timer_ms = 0.0; p.timer_count = 0;
+  MMNN_REQUIRE(kind >= -1 && kind < T_COUNT, "set_timer: unknown kernel class %d", kind);
+  p.timer_mask = kind < 0 ? ~1u : (kind == T_NONE ? 0u : 1u << kind);   // -1: every class
+  p.timer_block = block; p.timer_used = 0;
+  for (int k = 0; k < T_COUNT * MAX_BLOCKS; ++k) { p.timer_ms[k] = 0.0; p.timer_count[k] = 0; }
   return 0;
 }
 
-int plan_read_timer(Plan& p, double* total_ms, long* count) {
+int plan_read_timer(Plan& p, int kind, int block, double* total_ms, long* count) {
+  MMNN_REQUIRE(kind >= T_NONE && kind < T_COUNT && block < MAX_BLOCKS, "read_timer: unknown kernel class %d / block %d", kind, block);
   for (size_t i = 0; i + 1 < p.timer_used; i += 2) {
     MMNN_HIP(hipEventSynchronize(p.timer_ev[i + 1]));
     float ms = 0.f;
     MMNN_HIP(hipEventElapsedTime(&ms, p.timer_ev[i], p.timer_ev[i + 1]));
-    p.timer_ms += ms; p.timer_count += 1;
+    const int k = p.timer_tag[i / 2];
+    p.timer_ms[k] += ms; p.timer_count[k] += 1;
   }
   p.timer_used = 0;
-  if (total_ms) *total_ms = p.timer_ms;
-  if (count) *count = p.timer_count;
+  double ms = 0.0; long n = 0;
+  for (int k = 1; k < T_COUNT; ++k)         // class 0: all recorded classes together; block < 0: all blocks together
+    for (int b = 0; b < MAX_BLOCKS; ++b)
+      if ((kind == T_NONE || kind == k) && (block < 0 || block == b)) { ms += p.timer_ms[k * MAX_BLOCKS + b]; n += p.timer_count[k * MAX_BLOCKS + b]; }
+  if (total_ms) *total_ms = ms;
+  if (count) *count = n;
   return 0;
+}
+
+int plan_set_option(Plan& p, const char* name, long value) {
+  const std::string s(name ? name : "");
+  if (s == "single_stream") { p.single_stream = value != 0; return 0; }
+  set_error("set_option: unknown option '%s'", s.c_str());
+  return 1;
 }
 
 static DropCfg dropcfg(const Plan& p, uint64_t seed, int layer, int training) {
@@ -348,8 +373,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   build_tables(p, params, run, ws);
   MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
   if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
-  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, 4096 * sizeof(unsigned), stream));
-  kz_part_bytes = (size_t)512 * 4 * 1024 * sizeof(float); kz_cnt_entries = 4096;
+  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
   int rc = launch_pack(reinterpret_cast<const PackJob*>(ws + p.o_jobs_pack), p.n_pack_jobs, p.max_pack, stream);
   if (rc) return rc;
 
@@ -380,7 +404,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       const LayerOff& lo = p.layers[b][l];
       FpropArgs a;
       memset(&a, 0, sizeof(a));
-      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
       // conv1: ReLU(BN(concat)) -> T1
       a.Cin = lo.cin; a.M = p.mid;
@@ -395,7 +419,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       // conv2: ReLU(BN(T1)) -> growth new channels of the concat buffer (+ channel dropout)
       FpropArgs e;
       memset(&e, 0, sizeof(e));
-      e.kz_part = fptr(ws, p.o_kz_part); e.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(e, p, ws);
       e.N = N; e.D = p.Db[b]; e.H = p.Hb[b]; e.W = p.Wb[b];
       e.Cin = p.mid; e.M = c.growth;
       e.in0 = fptr(ws, p.o_t1[b][l]); e.in0_ns = (long)p.mid * p.Vb[b]; e.in0_coff = 0;
@@ -418,7 +442,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       if ((rc = launch_bnrelu_avgpool(q, stream))) return rc;
       FpropArgs a;
       memset(&a, 0, sizeof(a));
-      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b + 1]; a.H = p.Hb[b + 1]; a.W = p.Wb[b + 1];
       a.Cin = t.cin; a.M = t.cout;
       a.in0 = fptr(ws, p.o_ap[b]); a.in0_ns = (long)t.cin * p.Vb[b + 1]; a.in0_coff = 0;
@@ -451,19 +475,20 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   float* run = p.tab_run;
   int rc;
   MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
-  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, 4096 * sizeof(unsigned), stream));
+  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
   // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
   // kernels only consume its products, so they run beside it on `side`, ordered by events.  Matters for the late dense blocks
   // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
-  if (!p.side && !p.side_tried) {
+  static const bool env_single = [] { const char* e = getenv("MMNN_SINGLE_STREAM"); return e && e[0] == '1'; }();
+  const bool single = env_single || p.single_stream;   // profiling aid: serialise the backward on one stream (un-overlapped durations)
+  if (!single && !p.side && !p.side_tried) {
     p.side_tried = true;
-    const char* off = getenv("MMNN_SINGLE_STREAM");   // debugging / profiling aid: serialise the backward on one stream
-    if ((off && off[0] == '1') || hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
+    if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
     if (p.side && hipStreamCreateWithFlags(&p.side2, hipStreamNonBlocking) != hipSuccess) p.side2 = nullptr;
   }
-  hipStream_t side = p.side ? p.side : stream;                     // conv2 weight gradients (+ the big gradient finalise)
-  hipStream_t side2 = p.side2 ? p.side2 : side;                    // conv1 weight gradients
-  const bool two = p.side != nullptr;
+  hipStream_t side = (p.side && !single) ? p.side : stream;        // conv2 weight gradients (+ the big gradient finalise)
+  hipStream_t side2 = (p.side2 && !single) ? p.side2 : side;       // conv1 weight gradients
+  const bool two = side != stream;
   p.sync_used = 0;
   auto next_event = [&]() -> hipEvent_t {
     if (p.sync_used == p.sync_ev.size()) {
@@ -558,7 +583,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // conv2 data gradient -> dZ2 (ReLU mask of norm2 applied) + dgamma2/dbeta2
       FpropArgs a;
       memset(&a, 0, sizeof(a));
-      a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
       a.Cin = c.growth; a.M = p.mid;
       a.in0 = fptr(ws, p.o_g[b]); a.in0_ns = xns; a.in0_coff = lo.cin;
@@ -594,7 +619,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // conv1 data gradient -> G[0:cin) += gamma1 * mask * (...), dgamma1/dbeta1, S1/S2
       FpropArgs d;
       memset(&d, 0, sizeof(d));
-      d.kz_part = fptr(ws, p.o_kz_part); d.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(d, p, ws);
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
       d.Cin = p.mid; d.M = lo.cin;
       d.in0 = dz2; d.in0_ns = tns; d.in0_coff = 0;
@@ -654,7 +679,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       // transition conv data gradient -> gradient wrt the pooled activations
       FpropArgs d;
       memset(&d, 0, sizeof(d));
-      d.kz_part = fptr(ws, p.o_kz_part); d.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+      set_kz(d, p, ws);
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
       d.Cin = t.cout; d.M = t.cin;
       d.in0 = w.g0; d.in0_ns = xns; d.in0_coff = 0;

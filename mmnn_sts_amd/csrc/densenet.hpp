@@ -71,16 +71,19 @@ struct Plan {
   hipStream_t side = nullptr, side2 = nullptr; bool side_tried = false;   // conv2 / conv1 weight-gradient streams
   std::vector<hipEvent_t> sync_ev; size_t sync_used = 0;
   // optional live timing of one kernel class with HIP events (bench.py roofline leg)
-  int timer_kind = 0, timer_block = -1;            // kind: see TimerKind; block < 0: every block
+  unsigned timer_mask = 0; int timer_block = -1;   // bit k: class k of TimerKind is timed; block < 0: every block
   std::vector<hipEvent_t> timer_ev;                // start/stop pairs recorded since the last read
+  std::vector<int> timer_tag;                      // class of each pair
   size_t timer_used = 0;
-  double timer_ms = 0.0; long timer_count = 0;
+  double timer_ms[16 * MAX_BLOCKS] = {0}; long timer_count[16 * MAX_BLOCKS] = {0};   // [class][block]
+  bool single_stream = false;                      // option "single_stream": backward on the caller's stream only
 };
 
 enum TimerKind { T_NONE = 0, T_CONV2_FWD = 1, T_CONV2_DGRAD = 2, T_CONV2_WGRAD = 3, T_CONV1_FWD = 4, T_CONV1_DGRAD = 5,
-                 T_CONV1_WGRAD = 6, T_STEM_CONV = 7, T_STEM_WGRAD = 8 };
-int plan_set_timer(Plan& p, int kind, int block);
-int plan_read_timer(Plan& p, double* total_ms, long* count);
+                 T_CONV1_WGRAD = 6, T_STEM_CONV = 7, T_STEM_WGRAD = 8, T_COUNT = 9 };
+int plan_set_timer(Plan& p, int kind, int block);                              // kind -1: every class
+int plan_read_timer(Plan& p, int kind, int block, double* total_ms, long* count);   // kind 0 / block < 0: all of them together
+int plan_set_option(Plan& p, const char* name, long value);
 
 int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W);
 void plan_free(Plan& p);

@@ -6,8 +6,11 @@
 
 namespace mmnn {
 
-// capacity of the K-split scratch the plan provides (densenet.hip); the split is skipped when it would not fit
-size_t kz_part_bytes = 0, kz_cnt_entries = 0;
+int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev % MAX_DEVICES;
+}
 
 // defined (explicitly instantiated) in fprop_inst_*.hip, one translation unit per combination
 template <int TAPS, int PRO, int EPI>

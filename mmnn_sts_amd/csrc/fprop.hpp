@@ -39,10 +39,12 @@ struct FpropArgs {
   StatPtr s_acc;
   // cross-block K-split (gridDim.z slices of the channel axis): partial tiles + per-tile arrival counters (zero on entry)
   float* kz_part; unsigned* kz_cnt;
+  size_t kz_part_bytes; unsigned kz_cnt_entries;   // capacity of kz_part / kz_cnt as provided by the caller (the split is skipped when it would not fit)
 };
 
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream);
-extern size_t kz_part_bytes, kz_cnt_entries;   // capacity of FpropArgs::kz_part / kz_cnt as provided by the plan
+int current_device_slot();   // index of the calling thread's current HIP device, for per-device caches of kernel attributes
+constexpr int MAX_DEVICES = 32;
 
 #if defined(__HIPCC__)
 

@@ -8,9 +8,6 @@
 
 namespace mmnn {
 
-// capacity of the K-split scratch the plan provides (densenet.hip); the split is skipped when it would not fit
-extern size_t kz_part_bytes, kz_cnt_entries;
-
 template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
 static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   constexpr bool KZ_OK = (MT * NT == 1) || (TAPS == 27 && TW <= 16);   // only the small-extent tiles are ever short of blocks
@@ -22,10 +19,11 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
     static const char* env = getenv("MMNN_FPROP_MIN_SMEM");   // experiment knob: force fewer blocks per CU
     if (env) { size_t v = (size_t)atol(env); if (v > smem && v <= 160 * 1024) smem = v; }
   }
-  static size_t configured = 0;
-  if (smem > configured) {
+  static size_t configured[MAX_DEVICES] = {0};   // hipFuncSetAttribute is per device: remember the largest request of each
+  size_t& conf = configured[current_device_slot()];
+  if (smem > conf) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = smem;
+    conf = smem;
   }
   long tiles;
   if (TAPS == 27) tiles = (long)a.N * cdiv(a.D, TD) * cdiv(a.H, TH) * cdiv(a.W, TW);
@@ -40,7 +38,7 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
     while (kz * 2 <= nch && tiles * mtiles * kz * 2 <= 256 && kz < 8) kz *= 2;
     if (kz > 1) {
       const size_t need = (size_t)tiles * mtiles * kz * (WM * WN * MT * NT) * 1024 * sizeof(float);
-      if (need > kz_part_bytes || (size_t)tiles * mtiles > kz_cnt_entries) kz = 1;
+      if (need > a.kz_part_bytes || (size_t)tiles * mtiles > a.kz_cnt_entries) kz = 1;
     }
   }
   MMNN_LAUNCH(kern, dim3((unsigned)tiles, (unsigned)mtiles, (unsigned)kz), dim3(C::NTHREADS), smem, stream, a);

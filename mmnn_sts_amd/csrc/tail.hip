@@ -303,8 +303,8 @@ __global__ void __launch_bounds__(256) heads_bwd_kernel(const HeadsArgs a) {
 struct CoxArgs {
   int H, N, C;
   const float* preds;        // [H][N][C]
-  const long long* key;      // [N][C]
-  const long long* wgt;      // [N][C]
+  const double* key;         // [N][C]  (fp64 holds every int64 duration < 2^53 and every fp32 value exactly)
+  const double* wgt;         // [N][C]
   const float* hw;           // [H] blend weights (null: all 1)
   float* head_loss;          // [H]  (sum over targets)
   float* loss;               // [1]  sum_h hw[h] * head_loss[h]
@@ -325,10 +325,10 @@ __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE bl
     int* pos = reinterpret_cast<int*>(cs + N);          // original index of sorted slot
     __syncthreads();
     for (int i = tid; i < N; i += 256) {                // stable descending rank
-      const long long ki = a.key[i * a.C + c];
+      const double ki = a.key[i * a.C + c];
       int r = 0;
       for (int j = 0; j < N; ++j) {
-        const long long kj = a.key[j * a.C + c];
+        const double kj = a.key[j * a.C + c];
         r += (kj > ki) || (kj == ki && j < i);
       }
       hs[r] = a.preds[((long)h * N + i) * a.C + c];
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE bl
     if (tid == 0) {
       float g = -INFINITY;
       double W = 0.0;
-      for (int i = 0; i < N; ++i) { g = fmaxf(g, hs[i]); W += (double)a.wgt[pos[i] * a.C + c]; }
+      for (int i = 0; i < N; ++i) { g = fmaxf(g, hs[i]); W += a.wgt[pos[i] * a.C + c]; }
       float run = 0.f, num = 0.f;
       for (int i = 0; i < N; ++i) {
         run += expf(hs[i] - g);
@@ -523,14 +523,14 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
   return 0;
 }
 
-int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const int64_t* sort_key, const int64_t* weight,
+int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
                         const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream) {
   MMNN_REQUIRE(heads > 0 && n > 0 && c > 0 && heads * c <= 64 && preds && sort_key && weight && loss && head_losses && grad_preds && scratch,
                "cox_blend_loss: bad arguments (heads*targets must be <= 64)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   CoxArgs a;
-  a.H = heads; a.N = n; a.C = c; a.preds = preds; a.key = reinterpret_cast<const long long*>(sort_key);
-  a.wgt = reinterpret_cast<const long long*>(weight); a.hw = head_weights; a.head_loss = head_losses; a.loss = loss;
+  a.H = heads; a.N = n; a.C = c; a.preds = preds; a.key = sort_key;
+  a.wgt = weight; a.hw = head_weights; a.head_loss = head_losses; a.loss = loss;
   a.grad = grad_preds; a.scratch = scratch; a.eps = 1e-7f;
   MMNN_LAUNCH(cox_kernel, dim3(1), dim3(256), 0, s, a);
   MMNN_HIP(hipGetLastError());

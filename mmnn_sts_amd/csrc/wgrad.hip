@@ -43,10 +43,11 @@ static int launch3(const WgradArgs& a, hipStream_t stream) {
   using C = Wg3Cfg<TD, TH, TW>;
   auto kern = wgrad3_kernel<PRO_X, TD, TH, TW>;
   const size_t smem = C::smem_bytes();
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
+    conf = true;
   }
   MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32)), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
@@ -58,10 +59,11 @@ static int launch1(const WgradArgs& a, hipStream_t stream) {
   using C = Wg1Cfg<WC>;
   auto kern = wgrad1_kernel<PRO_X, WC>;
   const size_t smem = C::smem_bytes();
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
+    conf = true;
   }
   MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());

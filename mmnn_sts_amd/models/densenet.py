@@ -69,15 +69,38 @@ class _Backbone(nn.Sequential):
                 self.add_module(f"transition{i + 1}", trans)
                 c //= 2
         self.out_channels = c
-        # non-module state (kept out of state_dict)
+        self._reset_native_state()
+
+    # ---- native state: flat buffers + launch plans.  Owned by exactly ONE module object -------------------------------
+    _NATIVE_STATE = ("_flat", "_flat_run", "_flat_nbt", "_flat_grad", "_plans", "_anchor", "_params", "_bns", "_fwd_token",
+                     "_grads_attached", "_grads_stale")
+
+    def _reset_native_state(self) -> None:
+        """Non-module state (kept out of state_dict): nothing flattened, no plan.  Rebuilt lazily by the next forward."""
         object.__setattr__(self, "_flat", None)
         object.__setattr__(self, "_flat_run", None)
+        object.__setattr__(self, "_flat_nbt", None)
         object.__setattr__(self, "_flat_grad", None)
         object.__setattr__(self, "_plans", OrderedDict())
         object.__setattr__(self, "_anchor", None)
+        object.__setattr__(self, "_params", None)
+        object.__setattr__(self, "_bns", None)
         object.__setattr__(self, "_fwd_token", 0)
         object.__setattr__(self, "_grads_attached", False)
         object.__setattr__(self, "_grads_stale", True)
+
+    def __getstate__(self):
+        """copy.deepcopy(model) / torch.save(model) copy the module WITHOUT its native plan handles (raw pointers: two owners
+        would free them twice) and without the flat views; the copy re-flattens and re-plans on its first forward."""
+        state = super().__getstate__() if hasattr(nn.Module, "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        for k in self._NATIVE_STATE:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._reset_native_state()
 
     # ---- flat parameter storage -------------------------------------------------------------------------------------
     def _bn_modules(self):
@@ -193,7 +216,12 @@ class _Backbone(nn.Sequential):
             raise RuntimeError(f"model on {self._flat.device}, input on {x.device}")
         if self.training and torch.is_grad_enabled():
             return _BackboneFn.apply(x, self._anchor, self)
-        return self._run_forward(x, self.training)[0]
+        out = self._run_forward(x, self.training)[0]
+        if torch.is_grad_enabled() and not self.training:
+            # eval-mode forward keeps no activations: a later backward() must fail loudly instead of silently producing no
+            # backbone gradients (Grad-CAM has its own closed-form path: utils.MultiModalGradCAM)
+            return _NoBackward.apply(out, self._anchor)
+        return out
 
     def _run_forward(self, x, training):
         ent = self._plan_for(x)
@@ -267,6 +295,18 @@ class _BackboneFn(torch.autograd.Function):
         g = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.float().contiguous()
         ctx.module._run_backward(x, ctx.ent, ctx.seed, ctx.token, g)
         return None, None, None
+
+
+class _NoBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, anchor):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise RuntimeError("mmnn_sts_amd: backward through an eval-mode DenseNet backbone forward is not supported (no activations "
+                           "are kept in eval mode); call model.train() for training, wrap inference in torch.no_grad(), or use "
+                           "utils.MultiModalGradCAM for attention maps")
 
 
 class _Features(nn.Sequential):

@@ -3,6 +3,7 @@ forward/backward below is one or two launches of hand-written HIP kernels; there
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -30,9 +31,12 @@ _seed_counter = [0]
 
 
 def next_seed() -> int:
-    """Per-call dropout stream id, derived from torch's seed so `torch.manual_seed` makes runs repeatable."""
+    """Per-call dropout stream id, derived from torch's seed so `torch.manual_seed` makes runs repeatable, and from the
+    data-parallel rank so that ranks seeded alike still draw different masks."""
     _seed_counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    rank = int(os.environ.get("RANK", "0") or 0)
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03
+            + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -96,6 +100,8 @@ class MlpStack(torch.autograd.Function):
         n = x.shape[0]
         if x.dim() != 2 or x.shape[1] != dims_in[0]:
             raise ValueError(f"MLP stack expects (N, {dims_in[0]}) input, got {tuple(x.shape)}")
+        if training and n == 1:     # torch.nn.BatchNorm1d refuses this too (models/mlp.py:22-48 in training mode)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         seed = next_seed()
         desc = _mlp_desc(n, dims_in, dims_out, relu_first, p, eps, momentum, seed, training, first_id)
         pp = _lib.MlpParams()
@@ -205,15 +211,16 @@ class FusionHeads(torch.autograd.Function):
 # Cox partial likelihood, summed over targets, blended over heads
 # ----------------------------------------------------------------------------------------------------------------------
 class CoxBlend(torch.autograd.Function):
-    """preds (H, N, C); sort_key / weight (N, C) int64 in pycox's (durations, events) positions.  Returns
-    (loss, head_losses) with loss = sum_h head_weights[h] * head_losses[h]."""
+    """preds (H, N, C); sort_key / weight (N, C) in pycox's (durations, events) positions, any integer or floating dtype
+    (the reference's datasets produce int64 and float32; both travel as fp64, which holds them exactly -- fractional
+    durations are NOT truncated).  Returns (loss, head_losses) with loss = sum_h head_weights[h] * head_losses[h]."""
 
     @staticmethod
     def forward(ctx, preds, sort_key, weight, head_weights):
         _need_cuda(preds, sort_key, weight, head_weights)
         preds = _f32c(preds)
-        sort_key = sort_key.to(torch.int64).contiguous()
-        weight = weight.to(torch.int64).contiguous()
+        sort_key = sort_key.to(torch.float64).contiguous()
+        weight = weight.to(torch.float64).contiguous()
         h, n, c = preds.shape
         dev = preds.device
         hw = _f32c(head_weights) if head_weights is not None else None
