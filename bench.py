@@ -247,7 +247,7 @@ def main():
     # Initialisation (plan build, lazily created streams/events, allocator growth, clock ramp after the idle model build) takes
     # a handful of steps; they are run before the W warm-up steps when W itself is too small to cover them, and reported.
     init_steps = max(0, 8 - a.warmup)
-    total_steps = a.steps + a.warmup + init_steps + 1
+    total_steps = a.steps + a.warmup + init_steps + 1 + 8      # + the untimed steps of the roofline leg
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total_steps)
     blender = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion)
     inputs, events, durations = synth_batch(dev, rank, a.micro_batch, a.size)

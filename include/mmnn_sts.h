@@ -144,6 +144,13 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
 int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
                         const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream);
 
+/* ---- element-wise binary cross entropy on logits with per-class positive weights: nn.BCEWithLogitsLoss(pos_weight=...,
+ * reduction='none') of the classification trainer (main.py:147-153), the loss behind `criterion` (utils/utils.py:20-22) and
+ * GradientBlender.computeLossClassification (losses/GradientBlender.py:150-179).  logits / targets / loss / dloss_dlogits hold
+ * `total` floats whose fastest axis is the class axis of length c; pos_weight [c] or NULL; dloss_dlogits may be NULL. */
+int mmnn_bce_logits(int64_t total, int32_t c, const float* logits, const float* targets, const float* pos_weight, float* loss,
+                    float* dloss_dlogits, void* stream);
+
 /* ---- optimizer step over a flat buffer: torch.optim.SGD(momentum, nesterov, weight_decay) as main.py:410-413 uses it.
  * d = g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr * (nesterov ? d + momentum*buf : buf) */
 int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,

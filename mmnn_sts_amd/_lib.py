@@ -76,6 +76,7 @@ def lib():
         "mmnn_linear_backward": [I, I, I, V, V, V, V, V, V, I, V],
         "mmnn_cox_blend_loss": [I, I, I, V, V, V, V, V, V, V, V, V],
         "mmnn_sgd_step": [V, V, V, c_int64, F, F, F, I, I, V],
+        "mmnn_bce_logits": [c_int64, I, V, V, V, V, V, V],
         "mmnn_densenet_set_timer": [V, I, I],
         "mmnn_densenet_read_timer": [V, POINTER(ctypes.c_double), POINTER(c_int64)],
         "mmnn_densenet_read_timer_class": [V, I, I, POINTER(ctypes.c_double), POINTER(c_int64)],

@@ -405,11 +405,39 @@ __global__ void __launch_bounds__(256) linear_bwd_kernel(int N, int D, int O, co
     }
 }
 
+// =====================================================================================================================
+// element-wise binary cross entropy on logits with per-class positive weights -- nn.BCEWithLogitsLoss(pos_weight, reduction
+// ='none') as the classification trainer builds it (main.py:147-153), for `criterion` (utils/utils.py:20-22) and
+// GradientBlender.computeLossClassification (losses/GradientBlender.py:150-179).
+//   l = pw_c * y * softplus(-x) + (1 - y) * softplus(x),   dl/dx = (1 - y) * sigmoid(x) - pw_c * y * sigmoid(-x)
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) bce_logits_kernel(long total, int C, const float* x, const float* y, const float* pw, float* loss,
+                                                          float* dldx) {
+  for (long e = blockIdx.x * 256l + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const float xv = x[e], yv = y[e], w = pw ? pw[e % C] : 1.f;
+    const float ax = fabsf(xv), l1p = log1pf(expf(-ax));          // stable softplus: softplus(t) = max(t, 0) + log1p(exp(-|t|))
+    const float sp_pos = fmaxf(xv, 0.f) + l1p, sp_neg = fmaxf(-xv, 0.f) + l1p;
+    const float sg = 1.f / (1.f + expf(-xv));
+    loss[e] = w * yv * sp_neg + (1.f - yv) * sp_pos;
+    if (dldx) dldx[e] = (1.f - yv) * sg - w * yv * (1.f - sg);
+  }
+}
+
 }  // namespace mmnn
 
 using namespace mmnn;
 
 extern "C" {
+
+int mmnn_bce_logits(int64_t total, int32_t c, const float* logits, const float* targets, const float* pos_weight, float* loss,
+                    float* dloss_dlogits, void* stream) {
+  MMNN_REQUIRE(total > 0 && c > 0 && total % c == 0 && logits && targets && loss, "bce_logits: bad arguments");
+  const int blocks = (int)std::min<long>(1024, (total + 255) / 256);
+  MMNN_LAUNCH(bce_logits_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (long)total, (int)c, logits, targets,
+              pos_weight, loss, dloss_dlogits);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
 
 int mmnn_gap_linear_forward(int32_t n, int32_t c, int32_t v, int32_t f, const float* h, const float* w, const float* b, float* pooled,
                             float* out, float p, uint64_t seed, int32_t training, void* stream) {

@@ -22,3 +22,21 @@ def CoxPH(log_h, events, duration, intended_order: bool = False):
     if intended_order:
         return cox_ph_loss(log_h, duration, events)
     return cox_ph_loss(log_h, events, duration)
+
+
+class BCEWithLogitsLoss(torch.nn.Module):
+    """`nn.BCEWithLogitsLoss(pos_weight=..., reduction=...)` as the classification trainer builds it (main.py:147-153), on the
+    MI355X: the element-wise loss and its derivative come from one HIP kernel."""
+
+    def __init__(self, pos_weight=None, reduction: str = 'mean'):
+        super().__init__()
+        if reduction not in ('none', 'sum', 'mean'):
+            raise ValueError(f"{reduction} is not a valid value for reduction")
+        self.register_buffer('pos_weight', pos_weight)
+        self.reduction = reduction
+
+    def forward(self, input, target):
+        if target.shape != input.shape:
+            raise ValueError(f"Target size ({target.shape}) must be the same as input size ({input.shape})")
+        loss = ops.BceLogits.apply(input, target.to(input.dtype), self.pos_weight)
+        return loss if self.reduction == 'none' else (loss.sum() if self.reduction == 'sum' else loss.mean())

@@ -244,3 +244,31 @@ class CoxBlend(torch.autograd.Function):
             t = grad * (dheads / hw).view(-1, 1, 1)
             g = t if g is None else g + t
         return g, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# element-wise BCE on logits with positive-class weights  (classification trainer, main.py:147-153)
+# ----------------------------------------------------------------------------------------------------------------------
+class BceLogits(torch.autograd.Function):
+    """loss[...] = pw_c * y * softplus(-x) + (1 - y) * softplus(x), class axis last; no reduction."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, pos_weight):
+        _need_cuda(logits, targets, pos_weight)
+        x = _f32c(logits)
+        y = _f32c(targets.expand_as(logits) if targets.shape != logits.shape else targets)
+        c = x.shape[-1]
+        pw = _f32c(pos_weight) if pos_weight is not None else None
+        if pw is not None and pw.numel() != c:
+            raise ValueError(f"pos_weight has {pw.numel()} entries for {c} classes")
+        loss = torch.empty_like(x)
+        dldx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.lib().mmnn_bce_logits(x.numel(), c, x.data_ptr(), y.data_ptr(), pw.data_ptr() if pw is not None else None,
+                                              loss.data_ptr(), dldx.data_ptr() if dldx is not None else None, _stream()), "bce_logits")
+        ctx.save_for_backward(dldx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dldx,) = ctx.saved_tensors
+        return (dloss * dldx if dldx is not None else None), None, None

@@ -298,6 +298,54 @@ def g6_blender(out):
     np.savez_compressed(os.path.join(out, "g6_blender.npz"), **res)
 
 
+def g9_classification(out):
+    """Classification branch of the blender + the pos-weighted BCE of the classification trainer (reference main.py:147-156,
+    207-212, 264, 311-314; losses/GradientBlender.py:105-136,150-179; utils/utils.py:20-22), and the Cox loss on FRACTIONAL
+    (float32) durations / events as the reference's datasets build them (data/ImageDatasets.py:462)."""
+    from utils.utils import criterion  # noqa: E402  (reference)
+    res = {}
+    freqs = torch.tensor([0.3, 0.45])
+    pw = (torch.ones_like(freqs) - freqs) / freqs
+    res["pos_weight"] = pw.numpy()
+    bce_sum = torch.nn.BCEWithLogitsLoss(pos_weight=pw, reduction='sum')
+    bce_none = torch.nn.BCEWithLogitsLoss(pos_weight=pw, reduction='none')
+    n = 6
+    logits = torch.from_numpy(synth.uniform("cls/logits", (3, n, 2), 2.0)).requires_grad_(True)
+    targets = torch.from_numpy((synth.uniform("cls/targets", (n, 2)) > 0).astype(np.float32))
+    res["criterion_sum"] = np.array([criterion(bce_sum, logits[0], targets, "cpu").item()])
+    for red in ("sum", "mean"):
+        gb = GradientBlender(bce_none, reduction=red, device="cpu")
+        loss = gb.computeLoss(logits, targets)
+        g, = torch.autograd.grad(loss, logits)
+        res[f"{red}/loss"] = np.array([loss.item()])
+        res[f"{red}/grad"] = g.numpy()
+        res[f"{red}/heads"] = gb.computeLoss(logits, targets, reduceToHeads=True).detach().numpy()
+        res[f"{red}/history_len"] = np.array([len(gb.history)])
+    gb = GradientBlender(bce_none, device="cpu")
+    res["no_reduce"] = gb.computeLoss(logits, targets, no_reduce=True).detach().numpy()
+    # update sequence as train_classification feeds it: sigmoid probabilities for train, thresholded predictions for val
+    gb = GradientBlender(bce_none, device="cpu")
+    ws, ls = [], []
+    for it in range(3):
+        tp = torch.sigmoid(torch.from_numpy(synth.uniform(f"cls/train/{it}", (3, 12, 2), 2.0)))
+        vp = (torch.sigmoid(torch.from_numpy(synth.uniform(f"cls/val/{it}", (3, 10, 2), 2.0))) > 0.5).float()
+        tt = torch.from_numpy((synth.uniform("cls/tt", (12, 2)) > 0).astype(np.float32))
+        vt = torch.from_numpy((synth.uniform("cls/vt", (10, 2)) > 0).astype(np.float32))
+        gb.updateWeights(tp, tt, vp, vt)
+        ws.append(gb.weights.numpy().copy())
+        ls.append(np.stack([gb.ltn.numpy(), gb.lvn.numpy()]))
+    res["upd_weights"], res["upd_losses"], res["upd_history_len"] = np.stack(ws), np.stack(ls), np.array([len(gb.history)])
+    # Cox loss with fractional durations (float32 tensors, as torch.Tensor([...]) builds them upstream)
+    for n in (4, 9):
+        h = torch.from_numpy(synth.uniform(f"coxf/h{n}", (n, 2)))
+        ev = torch.from_numpy((synth.uniform(f"coxf/e{n}", (n, 2)) > -0.3).astype(np.float32))
+        ev[0] = 1
+        du = torch.from_numpy((synth.uniform(f"coxf/d{n}", (n, 2)) * 0.5 + 0.5).astype(np.float32) * 30.0 + 0.25)
+        res[f"coxf/n{n}"] = np.array([surv_criterion(CoxPH, h, ev, du, "cpu").item()])
+        res[f"coxf/n{n}/c0"] = np.array([CoxPH(h[:, 0], ev[:, 0], du[:, 0]).item()])
+    np.savez_compressed(os.path.join(out, "g9_classification.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -307,7 +355,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     jobs = {"g1": g1_mlp, "g2": g2_densenet, "g3": g3_g4_fusion, "g5": g5_gradcam, "g6": g6_blender, "g7": g7_tiny,
-            "g8": g8_unimodal}
+            "g8": g8_unimodal, "g9": g9_classification}
     big = {"g3big": lambda o: g3_g4_fusion(o, sizes=(128,)), "g5big": lambda o: [g5_gradcam(o, 128), g5_gradcam(o, 256)]}
     jobs.update(big)
     for k, fn in jobs.items():

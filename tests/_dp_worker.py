@@ -44,7 +44,7 @@ def backward_micro_batch(mm, i, dev):
     gb = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion)
     loss, _ = gb.computeLoss(mm(x), ev, du)
     loss.backward()
-    return float(loss)
+    return float(loss.detach())
 
 
 def main():

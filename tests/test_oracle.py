@@ -171,3 +171,56 @@ def test_gradcam():
     for i, m in enumerate(maps):
         np.testing.assert_allclose(m[:: s // 8, :: s // 8, :: s // 8].numpy(), g[f"map{i}_coarse"], rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(stat3(m), g[f"map{i}_stats"], rtol=1e-3, atol=1e-5)
+
+
+def _cls_inputs():
+    n = 6
+    logits = torch.from_numpy(synth.uniform("cls/logits", (3, n, 2), 2.0))
+    targets = torch.from_numpy((synth.uniform("cls/targets", (n, 2)) > 0).astype(np.float32))
+    return logits, targets
+
+
+def _cls_update_inputs(it):
+    tp = torch.sigmoid(torch.from_numpy(synth.uniform(f"cls/train/{it}", (3, 12, 2), 2.0)))
+    vp = (torch.sigmoid(torch.from_numpy(synth.uniform(f"cls/val/{it}", (3, 10, 2), 2.0))) > 0.5).float()
+    tt = torch.from_numpy((synth.uniform("cls/tt", (12, 2)) > 0).astype(np.float32))
+    vt = torch.from_numpy((synth.uniform("cls/vt", (10, 2)) > 0).astype(np.float32))
+    return tp, tt, vp, vt
+
+
+def test_classification_blender_and_bce():
+    """Oracle restatement of the classification branch (BCE-with-logits, blender, update sign) vs the reference (G9)."""
+    g = load_golden("g9_classification.npz")
+    pw = torch.from_numpy(g["pos_weight"])
+    logits, targets = _cls_inputs()
+    bce = lambda p, t: R.bce_with_logits(p, t, pw, "none")
+    np.testing.assert_allclose(R.bce_with_logits(logits[0], targets, pw, "sum").item(), g["criterion_sum"][0], rtol=1e-6)
+    for red in ("sum", "mean"):
+        x = logits.clone().requires_grad_(True)
+        b = R.ClassBlender(bce, red)
+        loss = b.compute_loss(x, targets)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"{red}/loss"][0], rtol=1e-6)
+        np.testing.assert_allclose(x.grad.numpy(), g[f"{red}/grad"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b.compute_loss(logits, targets, reduce_to_heads=True).numpy(), g[f"{red}/heads"], rtol=1e-6)
+        assert len(b.history) == int(g[f"{red}/history_len"][0]) == 1
+    np.testing.assert_allclose(R.ClassBlender(bce).compute_loss(logits, targets, no_reduce=True).numpy(), g["no_reduce"], rtol=1e-6)
+    b = R.ClassBlender(bce)
+    for it in range(3):
+        b.update_weights(*_cls_update_inputs(it))
+        np.testing.assert_allclose(b.weights.numpy(), g["upd_weights"][it], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(np.stack([b.ltn.numpy(), b.lvn.numpy()]), g["upd_losses"][it], rtol=1e-6)
+    assert len(b.history) == int(g["upd_history_len"][0]) == 1
+
+
+def test_cox_fractional_durations():
+    """float32 durations / events (data/ImageDatasets.py:462 builds them with torch.Tensor([...])) must not be truncated."""
+    g = load_golden("g9_classification.npz")
+    for n in (4, 9):
+        h = torch.from_numpy(synth.uniform(f"coxf/h{n}", (n, 2)))
+        ev = torch.from_numpy((synth.uniform(f"coxf/e{n}", (n, 2)) > -0.3).astype(np.float32))
+        ev[0] = 1
+        du = torch.from_numpy((synth.uniform(f"coxf/d{n}", (n, 2)) * 0.5 + 0.5).astype(np.float32) * 30.0 + 0.25)
+        np.testing.assert_allclose(R.surv_criterion(R.CoxPH, h, ev, du).item(), g[f"coxf/n{n}"][0], rtol=1e-6)
+        np.testing.assert_allclose(R.CoxPH(h[:, 0], ev[:, 0], du[:, 0]).item(), g[f"coxf/n{n}/c0"][0], rtol=1e-6)
+        assert abs(R.CoxPH(h[:, 0], ev[:, 0], du[:, 0].long().float()).item() - g[f"coxf/n{n}/c0"][0]) > 1e-4   # truncation would show
