@@ -151,6 +151,37 @@ int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds,
 int mmnn_bce_logits(int64_t total, int32_t c, const float* logits, const float* targets, const float* pos_weight, float* loss,
                     float* dloss_dlogits, void* stream);
 
+/* ---- 3-D ResNet-18 variant (models/resnet.py:5-227).  Generic direct kernels: the net is 8 / 16 channels wide. ---------------- */
+typedef struct {
+  int32_t n, c_in, d, h, w;      /* input  [n][c_in][d][h][w]  */
+  int32_t c_out;                 /* weight [c_out][c_in][kernel...], no bias (Conv3DSimple :95-112, BasicStem :9-11, downsample :176-178) */
+  int32_t kernel[3], stride[3], padding[3];
+} mmnn_conv3d_desc;
+int mmnn_conv3d_out_shape(const mmnn_conv3d_desc* d, int32_t* od, int32_t* oh, int32_t* ow);
+int mmnn_conv3d_forward(const mmnn_conv3d_desc* d, const float* x, const float* w, float* y, void* stream);
+/* autograd adjoints (main.py:469): dx [n][c_in][d][h][w];  dw [c_out][c_in][kernel...] (accumulate != 0: added to);
+ * workspace for the deterministic partial-sum slabs: mmnn_conv3d_wgrad_workspace_bytes(d) bytes */
+int mmnn_conv3d_backward_data(const mmnn_conv3d_desc* d, const float* dy, const float* w, float* dx, void* stream);
+int64_t mmnn_conv3d_wgrad_workspace_bytes(const mmnn_conv3d_desc* d);
+int mmnn_conv3d_backward_weight(const mmnn_conv3d_desc* d, const float* x, const float* dy, float* dw, void* workspace, int32_t accumulate,
+                                void* stream);
+/* nn.BatchNorm3d [+ residual add] [+ ReLU] [+ element-wise nn.Dropout]: the tail of BasicStem (:12-13), of both halves of a BasicBlock
+ * (:74-77, :89-91: `out += residual; out = relu(out)`), of a downsample branch (:179) and the dropout after each stage (:159-166).
+ * x / residual / out [n][c][v]; save [2][c] (mean, rstd) and stat_ws (2*c doubles) are caller-provided scratch; training != 0: batch
+ * statistics + running-stat update (unbiased variance), training == 0: running statistics, no dropout. */
+int mmnn_bn3d_forward(int32_t n, int32_t c, int64_t v, const float* x, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual,
+                      float dropout_prob, uint64_t seed, float* out, float* save, double* stat_ws, void* stream);
+/* adjoint: dx wrt the BN input, dresidual (may be NULL) wrt the added tensor, dgamma / dbeta [c] (overwritten) */
+int mmnn_bn3d_backward(int32_t n, int32_t c, int64_t v, const float* x, const float* out, const float* dout, const float* gamma,
+                       const float* save, int32_t training, int32_t relu, float dropout_prob, uint64_t seed, float* dx, float* dresidual,
+                       float* dgamma, float* dbeta, double* stat_ws, void* stream);
+/* AdaptiveAvgPool3d(1) -> flatten -> Linear(c, o) -> sigmoid (models/resnet.py:152-167); pooled [n][c] is kept for the backward */
+int mmnn_gap_fc_sigmoid_forward(int32_t n, int32_t c, int64_t v, int32_t o, const float* x, const float* w, const float* b, float* pooled,
+                                float* y, void* stream);
+int mmnn_gap_fc_sigmoid_backward(int32_t n, int32_t c, int64_t v, int32_t o, const float* w, const float* pooled, const float* y, const float* dy,
+                                 float* dw, float* db, float* dx, void* stream);
+
 /* ---- optimizer step over a flat buffer: torch.optim.SGD(momentum, nesterov, weight_decay) as main.py:410-413 uses it.
  * d = g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr * (nesterov ? d + momentum*buf : buf) */
 int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,

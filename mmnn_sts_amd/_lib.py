@@ -17,6 +17,11 @@ class DenseNetConfig(Structure):
     ]
 
 
+class Conv3dDesc(Structure):
+    _fields_ = [("n", c_int32), ("c_in", c_int32), ("d", c_int32), ("h", c_int32), ("w", c_int32), ("c_out", c_int32),
+                ("kernel", c_int32 * 3), ("stride", c_int32 * 3), ("padding", c_int32 * 3)]
+
+
 MLP_MAX_LAYERS = 8
 _FP = POINTER(c_float)
 
@@ -77,6 +82,14 @@ def lib():
         "mmnn_cox_blend_loss": [I, I, I, V, V, V, V, V, V, V, V, V],
         "mmnn_sgd_step": [V, V, V, c_int64, F, F, F, I, I, V],
         "mmnn_bce_logits": [c_int64, I, V, V, V, V, V, V],
+        "mmnn_conv3d_out_shape": [POINTER(Conv3dDesc), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)],
+        "mmnn_conv3d_forward": [POINTER(Conv3dDesc), V, V, V, V],
+        "mmnn_conv3d_backward_data": [POINTER(Conv3dDesc), V, V, V, V],
+        "mmnn_conv3d_backward_weight": [POINTER(Conv3dDesc), V, V, V, V, I, V],
+        "mmnn_bn3d_forward": [I, I, c_int64, V, V, V, V, V, F, F, I, I, V, F, U, V, V, V, V],
+        "mmnn_bn3d_backward": [I, I, c_int64, V, V, V, V, V, I, I, F, U, V, V, V, V, V, V],
+        "mmnn_gap_fc_sigmoid_forward": [I, I, c_int64, I, V, V, V, V, V, V],
+        "mmnn_gap_fc_sigmoid_backward": [I, I, c_int64, I, V, V, V, V, V, V, V, V],
         "mmnn_densenet_set_timer": [V, I, I],
         "mmnn_densenet_read_timer": [V, POINTER(ctypes.c_double), POINTER(c_int64)],
         "mmnn_densenet_read_timer_class": [V, I, I, POINTER(ctypes.c_double), POINTER(c_int64)],
@@ -86,6 +99,8 @@ def lib():
         fn = getattr(L, name)
         fn.restype = c_int32
         fn.argtypes = args
+    L.mmnn_conv3d_wgrad_workspace_bytes.restype = c_int64
+    L.mmnn_conv3d_wgrad_workspace_bytes.argtypes = [POINTER(Conv3dDesc)]
     L.mmnn_mlp_saved_floats.restype = c_int64
     L.mmnn_mlp_saved_floats.argtypes = [POINTER(MlpDesc)]
     _lib = L

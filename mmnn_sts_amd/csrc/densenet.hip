@@ -177,8 +177,10 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   p.o_jobs_run = cv.take(sizeof(RunStatJob) * p.n_run_jobs);
   p.o_jobs_pack = cv.take(sizeof(PackJob) * p.n_pack_jobs);
   p.o_jobs_grad = cv.take(sizeof(GradJob) * p.n_grad_jobs);
+  p.n_layers = nlayers;
+  p.o_wg_table = cv.take(sizeof(WgradArgs) * 2 * nlayers);     // [conv2 of every layer][conv1 of every layer], see plan_backward
   p.ws_bytes = cv.cur;
-  p.host_jobs_bytes = p.ws_bytes - p.o_jobs_run;
+  p.host_jobs_bytes = p.o_wg_table - p.o_jobs_run;
   if (p.host_jobs) { (void)hipHostFree(p.host_jobs); p.host_jobs = nullptr; }   // (re)allocated lazily by the first forward
   p.tab_params = nullptr; p.tab_run = nullptr; p.tab_ws = nullptr;
   return 0;
@@ -187,6 +189,8 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
 void plan_free(Plan& p) {
   if (p.host_jobs) (void)hipHostFree(p.host_jobs);
   p.host_jobs = nullptr;
+  if (p.wg_pinned) (void)hipHostFree(p.wg_pinned);
+  p.wg_pinned = nullptr;
   for (hipEvent_t e : p.timer_ev) (void)hipEventDestroy(e);
   p.timer_ev.clear();
   for (hipEvent_t e : p.sync_ev) (void)hipEventDestroy(e);
@@ -466,6 +470,43 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   return 0;
 }
 
+// Arguments of the two weight-gradient launches of dense layer (b, l): conv2 (3x3x3, `w2`) and conv1 (1x1x1, `w1`).
+static void layer_wgrad_args(const Plan& p, const float* params, float* run, char* ws, int b, int l, int layer_id, uint64_t seed,
+                             WgradArgs& w2, WgradArgs& w1) {
+  const NetCfg& c = p.cfg;
+  const int N = p.N;
+  const double cnt = (double)N * p.Vb[b];
+  const long xns = (long)p.ctot_b[b] * p.Vb[b], tns = (long)p.mid * p.Vb[b];
+  const LayerOff& lo = p.layers[b][l];
+  const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+  const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+  const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0);
+  float* dz2 = fptr(ws, p.o_dz2[b]) + (long)l * N * tns;
+  memset(&w2, 0, sizeof(w2));
+  w2.N = N; w2.D = p.Db[b]; w2.H = p.Hb[b]; w2.W = p.Wb[b];
+  w2.M = c.growth; w2.Cin = p.mid;
+  w2.g0 = fptr(ws, p.o_g[b]); w2.g0_ns = xns; w2.g0_coff = lo.cin;
+  w2.g1 = fptr(ws, p.o_x[b]); w2.g1_ns = xns; w2.g1_coff = lo.cin;
+  w2.gr.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);       // BN-backward of the layer's concat slice (gammas folded into G)
+  w2.gr.s = statptr(ws, p.o_s_x[b], p.ctot_b[b], lo.cin);
+  w2.gr.gamma = nullptr; w2.gr.inv_count = 1.0 / cnt; w2.gr.eps = c.eps;
+  w2.drop.seed = seed; w2.drop.layer = layer_id; w2.drop.p = c.dropout_p;
+  w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
+  w2.bn = bn2;
+  w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
+  memset(&w1, 0, sizeof(w1));
+  w1.N = N; w1.D = p.Db[b]; w1.H = p.Hb[b]; w1.W = p.Wb[b];
+  w1.M = p.mid; w1.Cin = lo.cin;
+  w1.g0 = dz2; w1.g0_ns = tns; w1.g0_coff = 0;
+  w1.g1 = fptr(ws, p.o_t1[b][l]); w1.g1_ns = tns; w1.g1_coff = 0;
+  w1.gr.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);             // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2
+  w1.gr.s = dg2;
+  w1.gr.gamma = params + lo.n2w; w1.gr.inv_count = 1.0 / cnt; w1.gr.eps = c.eps;
+  w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
+  w1.bn = bn1;
+  w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
+}
+
 int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params, int accumulate,
                   uint64_t seed, hipStream_t stream) {
   MMNN_REQUIRE(params && x && ws && grad_out && grad_params, "backward: null buffer");
@@ -510,9 +551,33 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   // Weight gradients are launched in groups of `grp` layers: one event record on the main stream per group.  Every record
   // costs the chain ~6 us (the next kernel waits for the barrier packet's signal instead of being chained by the command
   // processor), which is as long as a whole small-block kernel, so blocks 2-4 batch several layers per record.
-  struct PendingW { WgradArgs w2, w1; int b; };
-  std::vector<PendingW> pend;
-  static int grp_cfg[3] = {1, 2, 4};   // layers per group for >= 32768 / >= 4096 / fewer voxels per batch
+  // Device-resident argument tables of every layer's two weight-gradient launches (for the batched launches below).  Their
+  // content does not depend on the step (the dropout seed travels as a kernel argument), so they are uploaded only when a
+  // buffer moved -- in practice once.
+  {
+    const size_t bytes = sizeof(WgradArgs) * 2 * p.n_layers;
+    if (!p.wg_pinned) {
+      MMNN_HIP(hipHostMalloc(&p.wg_pinned, bytes, hipHostMallocDefault));
+      p.wg_shadow.assign(bytes, 0);
+      p.wg_uploaded = false;
+    }
+    std::vector<WgradArgs> tab(2 * p.n_layers);
+    int id = 0;
+    for (int b = 0; b < nb; ++b)
+      for (int l = 0; l < c.block_layers[b]; ++l, ++id) layer_wgrad_args(p, params, run, ws, b, l, id, 0, tab[id], tab[p.n_layers + id]);
+    if (!p.wg_uploaded || memcmp(tab.data(), p.wg_shadow.data(), bytes) != 0) {
+      if (p.wg_uploaded) MMNN_HIP(hipStreamSynchronize(stream));   // an earlier upload from the pinned buffer may still be in flight
+      memcpy(p.wg_pinned, tab.data(), bytes);
+      memcpy(p.wg_shadow.data(), tab.data(), bytes);
+      MMNN_HIP(hipMemcpyAsync(ws + p.o_wg_table, p.wg_pinned, bytes, hipMemcpyHostToDevice, stream));
+      p.wg_uploaded = true;
+    }
+  }
+  const WgradArgs* dev_w2 = reinterpret_cast<const WgradArgs*>(ws + p.o_wg_table);
+  const WgradArgs* dev_w1 = dev_w2 + p.n_layers;
+  struct PendingW { WgradArgs w2, w1; int b, id; };
+  std::vector<PendingW> pend;        // consecutive layers in DESCENDING layer id
+  static int grp_cfg[3] = {1, 4, 8};   // layers per group for >= 32768 / >= 4096 / fewer voxels per batch
   static const bool grp_init = [] {
     const char* e = getenv("MMNN_WGRAD_GROUP");   // experiment knob: "a,b,c"
     if (e) sscanf(e, "%d,%d,%d", &grp_cfg[0], &grp_cfg[1], &grp_cfg[2]);
@@ -520,6 +585,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     return true;
   }();
   (void)grp_init;
+  static const bool no_batch = [] { const char* e = getenv("MMNN_NO_WGRAD_BATCH"); return e && e[0] == '1'; }();   // debugging aid
   auto flush = [&]() -> int {
     if (pend.empty()) return 0;
     int rc2;
@@ -530,13 +596,37 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       MMNN_HIP(hipStreamWaitEvent(side, e, 0));
       if (side2 != side) MMNN_HIP(hipStreamWaitEvent(side2, e, 0));
     }
-    for (const PendingW& q : pend) {
-      { ScopedTimer t(p, T_CONV2_WGRAD, q.b, side); rc2 = launch_wgrad(q.w2, 27, PRO_BNRELU, side); }
+    // The layers of a group are independent: ONE launch per kernel variant covers them all (blockIdx.z = layer).  pend holds
+    // descending layer ids, so a run [i, j) of it is the ascending table range [pend[j-1].id, pend[i].id].
+    const int np = (int)pend.size();
+    std::vector<WgradArgs> host(np);
+    if (np > 1 && !no_batch) {
+      for (int i = 0; i < np; ++i) host[np - 1 - i] = pend[i].w2;
+      { ScopedTimer t(p, T_CONV2_WGRAD, pend[0].b, side); rc2 = launch_wgrad_batched(host.data(), dev_w2 + pend[np - 1].id, np, seed, 27, PRO_BNRELU, side); }
       if (rc2) return rc2;
-    }
-    for (const PendingW& q : pend) {
-      { ScopedTimer t(p, T_CONV1_WGRAD, q.b, side2); rc2 = launch_wgrad(q.w1, 1, PRO_BNRELU, side2); }
-      if (rc2) return rc2;
+      for (int i = 0; i < np;) {       // conv1: runs of equal channel-group width (monotonic in the layer index)
+        int j = i + 1;
+        while (j < np && wgrad1_channel_width(pend[j].w1.Cin) == wgrad1_channel_width(pend[i].w1.Cin)) ++j;
+        if (j - i > 1) {
+          for (int k = i; k < j; ++k) host[j - 1 - k] = pend[k].w1;
+          ScopedTimer t(p, T_CONV1_WGRAD, pend[i].b, side2);
+          rc2 = launch_wgrad_batched(host.data(), dev_w1 + pend[j - 1].id, j - i, seed, 1, PRO_BNRELU, side2);
+        } else {
+          ScopedTimer t(p, T_CONV1_WGRAD, pend[i].b, side2);
+          rc2 = launch_wgrad(pend[i].w1, 1, PRO_BNRELU, side2);
+        }
+        if (rc2) return rc2;
+        i = j;
+      }
+    } else {
+      for (const PendingW& q : pend) {
+        { ScopedTimer t(p, T_CONV2_WGRAD, q.b, side); rc2 = launch_wgrad(q.w2, 27, PRO_BNRELU, side); }
+        if (rc2) return rc2;
+      }
+      for (const PendingW& q : pend) {
+        { ScopedTimer t(p, T_CONV1_WGRAD, q.b, side2); rc2 = launch_wgrad(q.w1, 1, PRO_BNRELU, side2); }
+        if (rc2) return rc2;
+      }
     }
     pend.clear();
     return 0;
@@ -598,17 +688,8 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       a.dbeta = dg2.sum; a.dgamma = dg2.sq;
       { ScopedTimer t(p, T_CONV2_DGRAD, b, stream); rc = launch_fprop(a, 27, PRO_GRAD, EPI_MASK_STORE, stream); }
       if (rc) return rc;
-      // conv2 weight gradient
-      WgradArgs w2;
-      memset(&w2, 0, sizeof(w2));
-      w2.N = N; w2.D = p.Db[b]; w2.H = p.Hb[b]; w2.W = p.Wb[b];
-      w2.M = c.growth; w2.Cin = p.mid;
-      w2.g0 = a.in0; w2.g0_ns = xns; w2.g0_coff = lo.cin;
-      w2.g1 = a.in1; w2.g1_ns = xns; w2.g1_coff = lo.cin;
-      w2.gr = a.gr_in; w2.drop = drop;
-      w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
-      w2.bn = bn2;
-      w2.slab = fptr(ws, p.o_sl_c2[b][l]); w2.slab_stride = (long)27 * c.growth * p.mid; w2.nsplit = p.ns_c2[b][l];
+      WgradArgs w2, w1;
+      layer_wgrad_args(p, params, run, ws, b, l, layer_id, seed, w2, w1);
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
@@ -633,21 +714,10 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       d.s_acc = sptr(b, 0);
       { ScopedTimer t(p, T_CONV1_DGRAD, b, stream); rc = launch_fprop(d, 1, PRO_GRAD, EPI_MASK_ACCUM, stream); }
       if (rc) return rc;
-      // conv1 weight gradient
-      WgradArgs w1;
-      memset(&w1, 0, sizeof(w1));
-      w1.N = N; w1.D = p.Db[b]; w1.H = p.Hb[b]; w1.W = p.Wb[b];
-      w1.M = p.mid; w1.Cin = lo.cin;
-      w1.g0 = d.in0; w1.g0_ns = tns; w1.g0_coff = 0;
-      w1.g1 = d.in1; w1.g1_ns = tns; w1.g1_coff = 0;
-      w1.gr = g1;
-      w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
-      w1.bn = bn1;
-      w1.slab = fptr(ws, p.o_sl_c1[b][l]); w1.slab_stride = (long)p.mid * lo.cin; w1.nsplit = p.ns_c1[b][l];
       // both weight gradients of this layer can run from here on (its G slice was final before conv2 dgrad, dZ2 and
       // dgamma2/dbeta2 since conv2 dgrad): queue them for the side streams
       PendingW pw;
-      pw.w2 = w2; pw.w1 = w1; pw.b = b;
+      pw.w2 = w2; pw.w1 = w1; pw.b = b; pw.id = layer_id;
       pend.push_back(pw);
       if ((int)pend.size() >= grp || l == 0) {
         if ((rc = flush())) return rc;

@@ -1,6 +1,8 @@
 // Host-side dispatch of the weight-gradient kernels (wgrad.hpp).
 #include "wgrad.hpp"
 
+#include <algorithm>
+
 namespace mmnn {
 
 static void wg3_tile(int W, int& TD, int& TH, int& TW) {
@@ -68,6 +70,72 @@ static int launch1(const WgradArgs& a, hipStream_t stream) {
   MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
+}
+
+int wgrad1_channel_width(int Cin) { return 32 * wg1_wc(Cin); }
+
+template <int PRO_X, int TD, int TH, int TW>
+static int launch3_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream) {
+  using C = Wg3Cfg<TD, TH, TW>;
+  auto kern = wgrad3_batched_kernel<PRO_X, TD, TH, TW>;
+  const size_t smem = C::smem_bytes();
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    conf = true;
+  }
+  int gx = 1, gy = 1;
+  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32)); }
+  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int PRO_X, int WC>
+static int launch1_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream) {
+  using C = Wg1Cfg<WC>;
+  auto kern = wgrad1_batched_kernel<PRO_X, WC>;
+  const size_t smem = C::smem_bytes();
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    conf = true;
+  }
+  int gx = 1, gy = 1;
+  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32 * WC)); }
+  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, int taps, int pro_x, hipStream_t stream) {
+  MMNN_REQUIRE(host && dev && count >= 1 && count <= 65535, "wgrad batch: bad table (count %d)", count);
+  MMNN_REQUIRE(pro_x == PRO_BNRELU, "wgrad batch: only the dense-layer kernels (BN+ReLU input prologue) are batched");
+  MMNN_REQUIRE(taps == 1 || taps == 27, "wgrad: taps must be 1 or 27");
+  const WgradArgs& f = host[0];
+  for (int i = 0; i < count; ++i) {
+    const WgradArgs& a = host[i];
+    MMNN_REQUIRE(a.N == f.N && a.D == f.D && a.H == f.H && a.W == f.W && a.M == f.M, "wgrad batch: layer %d differs in extent", i);
+    MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "wgrad: non-positive extent");
+    MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "wgrad: volume too large for 32-bit voxel indices");
+    MMNN_REQUIRE(a.g0 && a.g1 && a.x && a.slab, "wgrad: null operand");
+    MMNN_REQUIRE(a.nsplit >= 1 && a.nsplit <= 65535, "wgrad: bad split count %d", a.nsplit);
+    MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");
+    MMNN_REQUIRE(taps == 27 ? a.M <= 32 : a.M <= 128, "wgrad batch: %d output channels exceed one block row", a.M);
+    MMNN_REQUIRE(taps == 27 || wg1_wc(a.Cin) == wg1_wc(f.Cin), "wgrad batch: layer %d needs another channel-group width", i);
+  }
+  if (taps == 27) {
+    if (f.W > 16) return launch3_batched<PRO_BNRELU, 1, 2, 32>(host, dev, count, seed, stream);
+    if (f.W > 8) return launch3_batched<PRO_BNRELU, 1, 4, 16>(host, dev, count, seed, stream);
+    if (f.W > 4) return launch3_batched<PRO_BNRELU, 2, 4, 8>(host, dev, count, seed, stream);
+    return launch3_batched<PRO_BNRELU, 4, 4, 4>(host, dev, count, seed, stream);
+  }
+  const int wc = wg1_wc(f.Cin);
+  if (wc == 8) return launch1_batched<PRO_BNRELU, 8>(host, dev, count, seed, stream);
+  if (wc == 4) return launch1_batched<PRO_BNRELU, 4>(host, dev, count, seed, stream);
+  return launch1_batched<PRO_BNRELU, 2>(host, dev, count, seed, stream);
 }
 
 template <int PRO_X>

@@ -34,6 +34,11 @@ struct WgradArgs {
 };
 
 int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream);
+// `count` layers of identical extent (N, D, H, W), M and prologue in one launch.  host: the arguments (validated here);
+// dev_table: the same `count` entries in device memory (already uploaded); seed: this step's dropout seed (overrides drop.seed).
+// For taps == 1 every entry must select the same channel-group width (wgrad1_channel_width(Cin)).
+int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev_table, int count, uint64_t seed, int taps, int pro_x, hipStream_t stream);
+int wgrad1_channel_width(int Cin);   // input channels per block of the 1x1x1 kernel: 64, 128 or 256
 int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin);
 
 #if defined(__HIPCC__)
@@ -88,7 +93,7 @@ __device__ __forceinline__ void wg3_mfma(f32x16 (&acc)[4], const float* yl, cons
 }
 
 template <int PRO_X, int TD, int TH, int TW>
-__global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split, const int cg) {
   using C = Wg3Cfg<TD, TH, TW>;
   constexpr int RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS, YS = C::YS, NTHREADS = C::NTHREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -99,7 +104,6 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
   float* gbase = xcoef + 64;        // p,q,r before the per-sample dropout scale
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int V = a.D * a.H * a.W;
-  const int split = blockIdx.x, cg = blockIdx.y;
   const int c0 = cg * 32;
   const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;
   const int tiles_per_n = nw * nh * nd;
@@ -331,6 +335,22 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
   }
 }
 
+template <int PRO_X, int TD, int TH, int TW>
+__global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
+  wgrad3_body<PRO_X, TD, TH, TW>(a, blockIdx.x, blockIdx.y);
+}
+
+// Several layers in ONE launch (blockIdx.z = layer): the late dense blocks' weight gradients are a few dozen blocks per layer
+// each, far too few for 256 CUs, and independent of one another once the data-gradient chain has passed their layers.  The
+// argument table lives in device memory and is step-invariant; the per-step dropout seed arrives as a kernel argument.
+template <int PRO_X, int TD, int TH, int TW>
+__global__ void __launch_bounds__(512) wgrad3_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed) {
+  WgradArgs a = table[blockIdx.z];
+  if ((int)blockIdx.x >= a.nsplit || (int)blockIdx.y * 32 >= a.Cin) return;   // grid = the largest layer of the batch
+  a.drop.seed = seed;
+  wgrad3_body<PRO_X, TD, TH, TW>(a, blockIdx.x, blockIdx.y);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // 1x1x1:  block = WC waves, each owning 32 input channels x all 128 rows of one m-group (4 accumulator tiles).
 // ----------------------------------------------------------------------------------------------------------------
@@ -342,7 +362,7 @@ struct Wg1Cfg {
 };
 
 template <int PRO_X, int WC>
-__global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split, const int c0, const int m0) {
   using C = Wg1Cfg<WC>;
   constexpr int S = C::S, VK = C::VK, NTHREADS = C::NTHREADS, CB = 32 * WC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -353,7 +373,6 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
   float* gbase = xcoef + 2 * CB;     // p,q,r before the per-sample dropout scale
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int V = a.D * a.H * a.W;
-  const int split = blockIdx.x, c0 = blockIdx.y * CB, m0 = blockIdx.z * 128;
   const int chunks_per_n = (V + VK - 1) / VK;
   const int nchunks = a.N * chunks_per_n;
   const int k_begin = (int)((long)nchunks * split / a.nsplit), k_end = (int)((long)nchunks * (split + 1) / a.nsplit);
@@ -551,6 +570,20 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
       const int m = m0 + t * 32 + acc_row(r, half);
       if (m < a.M && c < a.Cin) out[(long)m * a.Cin + c] = acc[t][r];
     }
+}
+
+template <int PRO_X, int WC>
+__global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
+  wgrad1_body<PRO_X, WC>(a, blockIdx.x, blockIdx.y * (32 * WC), blockIdx.z * 128);
+}
+
+// several layers in one launch (blockIdx.z = layer; every layer of a batch has M <= 128): see wgrad3_batched_kernel
+template <int PRO_X, int WC>
+__global__ void __launch_bounds__(WC * 64) wgrad1_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed) {
+  WgradArgs a = table[blockIdx.z];
+  if ((int)blockIdx.x >= a.nsplit || (int)blockIdx.y * (32 * WC) >= a.Cin) return;
+  a.drop.seed = seed;
+  wgrad1_body<PRO_X, WC>(a, blockIdx.x, blockIdx.y * (32 * WC), 0);
 }
 
 #endif  // __HIPCC__

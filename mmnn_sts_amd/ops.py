@@ -272,3 +272,130 @@ class BceLogits(torch.autograd.Function):
     def backward(ctx, dloss):
         (dldx,) = ctx.saved_tensors
         return (dloss * dldx if dldx is not None else None), None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 3-D ResNet-18 variant  (models/resnet.py:5-227): direct convolution, BN [+ residual] [+ ReLU] [+ dropout], pooled sigmoid head
+# ----------------------------------------------------------------------------------------------------------------------
+def _triple(v):
+    return tuple(int(t) for t in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+def _conv_desc(x_shape, c_out, kernel, stride, padding):
+    n, c, d, h, w = x_shape
+    return _lib.Conv3dDesc(n, c, d, h, w, c_out, (ctypes.c_int32 * 3)(*kernel), (ctypes.c_int32 * 3)(*stride), (ctypes.c_int32 * 3)(*padding))
+
+
+class Conv3dDirect(torch.autograd.Function):
+    """y = conv3d(x, w, stride, padding), no bias, any kernel extent (Conv3DSimple, BasicStem conv, downsample conv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        _need_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        if x.dim() != 5 or weight.dim() != 5 or x.shape[1] != weight.shape[1]:
+            raise ValueError(f"conv3d: input {tuple(x.shape)} does not match weight {tuple(weight.shape)}")
+        stride, padding = _triple(stride), _triple(padding)
+        desc = _conv_desc(x.shape, weight.shape[0], tuple(weight.shape[2:]), stride, padding)
+        L = _lib.lib()
+        o = [ctypes.c_int32() for _ in range(3)]
+        _lib.check(L.mmnn_conv3d_out_shape(ctypes.byref(desc), *[ctypes.byref(v) for v in o]), "conv3d_out_shape")
+        y = torch.empty((x.shape[0], weight.shape[0], o[0].value, o[1].value, o[2].value), device=x.device, dtype=torch.float32)
+        _lib.check(L.mmnn_conv3d_forward(ctypes.byref(desc), x.data_ptr(), weight.data_ptr(), y.data_ptr(), _stream()), "conv3d_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.geom
+        dy = _f32c(dy)
+        desc = _conv_desc(x.shape, weight.shape[0], tuple(weight.shape[2:]), stride, padding)
+        L = _lib.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.mmnn_conv3d_backward_data(ctypes.byref(desc), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _stream()), "conv3d_backward_data")
+        dw = torch.empty_like(weight)
+        ws = torch.empty((L.mmnn_conv3d_wgrad_workspace_bytes(ctypes.byref(desc)),), dtype=torch.uint8, device=x.device)
+        _lib.check(L.mmnn_conv3d_backward_weight(ctypes.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, _stream()),
+                   "conv3d_backward_weight")
+        return dx, dw, None, None
+
+
+class BatchNormAct3d(torch.autograd.Function):
+    """out = dropout(relu?(BN(x) [+ residual])); running statistics are updated in place in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, momentum, eps, training, relu, drop_p):
+        _need_cuda(x, gamma, beta, running_mean, running_var, residual)
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        res = _f32c(residual) if residual is not None else None
+        if res is not None and res.shape != x.shape:
+            raise ValueError(f"residual {tuple(res.shape)} does not match {tuple(x.shape)}")
+        n, c = x.shape[0], x.shape[1]
+        v = x[0, 0].numel()
+        out = torch.empty_like(x)
+        save = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        stat = torch.empty((2, c), device=x.device, dtype=torch.float64)
+        seed = next_seed()
+        _lib.check(_lib.lib().mmnn_bn3d_forward(n, c, v, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                                running_var.data_ptr(), float(momentum), float(eps), int(training), int(relu),
+                                                res.data_ptr() if res is not None else None, float(drop_p), seed, out.data_ptr(),
+                                                save.data_ptr(), stat.data_ptr(), _stream()), "bn3d_forward")
+        ctx.save_for_backward(x, out, gamma, save)
+        ctx.meta = (int(training), int(relu), float(drop_p), seed, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, gamma, save = ctx.saved_tensors
+        training, relu, drop_p, seed, has_res = ctx.meta
+        dout = _f32c(dout)
+        n, c = x.shape[0], x.shape[1]
+        v = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[5]) else None
+        dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+        db = torch.empty((c,), device=x.device, dtype=torch.float32)
+        stat = torch.empty((2, c), device=x.device, dtype=torch.float64)
+        _lib.check(_lib.lib().mmnn_bn3d_backward(n, c, v, x.data_ptr(), out.data_ptr(), dout.data_ptr(), gamma.data_ptr(), save.data_ptr(),
+                                                 training, relu, drop_p, seed, dx.data_ptr(), dres.data_ptr() if dres is not None else None,
+                                                 dg.data_ptr(), db.data_ptr(), stat.data_ptr(), _stream()), "bn3d_backward")
+        return dx, dg, db, None, None, dres, None, None, None, None, None
+
+
+class GapFcSigmoid(torch.autograd.Function):
+    """sigmoid(Linear(mean over voxels))  (models/resnet.py:152-167)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_cuda(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        n, c = x.shape[0], x.shape[1]
+        v = x[0, 0].numel()
+        o = weight.shape[0]
+        pooled = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        y = torch.empty((n, o), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_gap_fc_sigmoid_forward(n, c, v, o, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), pooled.data_ptr(),
+                                                          y.data_ptr(), _stream()), "gap_fc_sigmoid_forward")
+        ctx.save_for_backward(weight, pooled, y)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, pooled, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, c = ctx.shape[0], ctx.shape[1]
+        v = 1
+        for t in ctx.shape[2:]:
+            v *= t
+        dx = torch.empty(ctx.shape, device=weight.device, dtype=torch.float32)
+        dw = torch.empty_like(weight)
+        db = torch.empty((weight.shape[0],), device=weight.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mmnn_gap_fc_sigmoid_backward(n, c, v, weight.shape[0], weight.data_ptr(), pooled.data_ptr(), y.data_ptr(),
+                                                           dy.data_ptr(), dw.data_ptr(), db.data_ptr(), dx.data_ptr(), _stream()),
+                   "gap_fc_sigmoid_backward")
+        return dx, dw, db

@@ -346,6 +346,34 @@ def g9_classification(out):
     np.savez_compressed(os.path.join(out, "g9_classification.npz"), **res)
 
 
+def g10_r3d18(out):
+    """r3d_18 (reference models/resnet.py:202-227): training forward (dropout forced to 0) + backward of sum(out * cot), running
+    statistics, eval forward."""
+    from models.resnet import r3d_18  # noqa: E402  (reference)
+    res = {}
+    for tag, shape in (("a", (2, 1, 16, 64, 64)), ("b", (3, 1, 9, 40, 52))):
+        m = r3d_18(2)
+        load_synth(m, "r3d.")
+        zero_dropout(m)
+        m.train()
+        x = torch.from_numpy(synth.uniform(f"r3d/x/{tag}", shape))
+        y = m(x)
+        cot = torch.from_numpy(synth.uniform(f"r3d/cot/{tag}", tuple(y.shape)))
+        (y * cot).sum().backward()
+        res[f"{tag}/out"] = y.detach().numpy()
+        for k, v in grad_probes(m).items():
+            res[f"{tag}/{k}"] = v
+        for k in ("fc.weight", "fc.bias", "stem.0.weight", "stem.1.weight", "layer1.0.downsample.0.weight", "layer4.1.conv2.0.weight",
+                  "layer2.0.conv1.0.weight", "layer3.0.downsample.1.bias"):
+            res[f"{tag}/grad/{k}"] = dict(m.named_parameters())[k].grad.numpy()
+        for k, v in bn_running(m).items():
+            res[f"{tag}/{k}"] = v
+        m.eval()
+        with torch.no_grad():
+            res[f"{tag}/eval_out"] = m(x).numpy()
+    np.savez_compressed(os.path.join(out, "g10_r3d18.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -355,7 +383,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     jobs = {"g1": g1_mlp, "g2": g2_densenet, "g3": g3_g4_fusion, "g5": g5_gradcam, "g6": g6_blender, "g7": g7_tiny,
-            "g8": g8_unimodal, "g9": g9_classification}
+            "g8": g8_unimodal, "g9": g9_classification, "g10": g10_r3d18}
     big = {"g3big": lambda o: g3_g4_fusion(o, sizes=(128,)), "g5big": lambda o: [g5_gradcam(o, 128), g5_gradcam(o, 256)]}
     jobs.update(big)
     for k, fn in jobs.items():

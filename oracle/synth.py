@@ -52,7 +52,8 @@ def synth_state_dict(shapes: dict, prefix: str = "") -> dict:
         full = prefix + key
         leaf = key.split(".")[-1]
         parent = key.split(".")[-2] if "." in key else ""
-        is_bn = parent.startswith("norm") or parent.startswith("bn")
+        is_bn = parent.startswith("norm") or parent.startswith("bn") or (leaf in ("weight", "bias") and len(shape) == 1 and (
+            key.rsplit(".", 1)[0] + ".running_mean") in shapes)
         if leaf == "num_batches_tracked":
             out[key] = np.zeros((), dtype=np.int64)
         elif leaf == "running_mean":

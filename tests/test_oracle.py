@@ -224,3 +224,24 @@ def test_cox_fractional_durations():
         np.testing.assert_allclose(R.surv_criterion(R.CoxPH, h, ev, du).item(), g[f"coxf/n{n}"][0], rtol=1e-6)
         np.testing.assert_allclose(R.CoxPH(h[:, 0], ev[:, 0], du[:, 0]).item(), g[f"coxf/n{n}/c0"][0], rtol=1e-6)
         assert abs(R.CoxPH(h[:, 0], ev[:, 0], du[:, 0].long().float()).item() - g[f"coxf/n{n}/c0"][0]) > 1e-4   # truncation would show
+
+
+@pytest.mark.parametrize("tag,shape", [("a", (2, 1, 16, 64, 64)), ("b", (3, 1, 9, 40, 52))])
+def test_r3d18(tag, shape):
+    """Oracle restatement of r3d_18 (models/resnet.py:202-227) vs the reference's own class (G10)."""
+    g = load_golden("g10_r3d18.npz")
+    sch = R.resnet18_schema(2)
+    assert len(sch) == 128
+    sd = synth_sd(sch, "r3d.", requires_grad=True)
+    x = torch.from_numpy(synth.uniform(f"r3d/x/{tag}", shape))
+    y = R.resnet18_forward(sd, x, True)
+    cot = torch.from_numpy(synth.uniform(f"r3d/cot/{tag}", tuple(y.shape)))
+    (y * cot).sum().backward()
+    assert rel_err(y.detach().numpy(), g[f"{tag}/out"]) < RTOL
+    for k in ("fc.weight", "stem.0.weight", "layer1.0.downsample.0.weight", "layer4.1.conv2.0.weight", "layer3.0.downsample.1.bias"):
+        assert rel_err(sd[k].grad.numpy(), g[f"{tag}/grad/{k}"]) < 1e-4, k
+    for k, v in zip(g[f"{tag}/running_names"], g[f"{tag}/running_chk"]):
+        t = sd[str(k)].double()
+        np.testing.assert_allclose([t.sum().item(), t.abs().sum().item()], v, rtol=1e-5)
+    with torch.no_grad():
+        assert rel_err(R.resnet18_forward(sd, x, False).numpy(), g[f"{tag}/eval_out"]) < RTOL
