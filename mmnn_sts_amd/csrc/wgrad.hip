@@ -20,8 +20,9 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
     wg3_tile(W, TD, TH, TW);
     const long ntiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
     const int cgroups = cdiv(Cin, 32);
-    long s = 512 / cgroups;
-    if (s > 64) s = 64;
+    static const int cap = [] { const char* e = getenv("MMNN_WG3_SPLIT_CAP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+    long s = (cap > 64 ? 1024 : 512) / cgroups;
+    if (s > cap) s = cap;
     if (s > ntiles / 2) s = ntiles / 2;
     return s < 1 ? 1 : (int)s;
   }

@@ -38,9 +38,10 @@ def gradient_buckets(model: torch.nn.Module) -> List[torch.Tensor]:
     return buckets
 
 
-def allreduce_gradients(model: torch.nn.Module, group=None) -> None:
-    """SUM all-reduce of every gradient; the small tensors travel as one coalesced flat buffer."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def allreduce_gradients(model: torch.nn.Module, group=None, force: bool = False) -> None:
+    """SUM all-reduce of every gradient; the small tensors travel as one coalesced flat buffer.  A single-rank group is a
+    no-op unless `force` (used by the tests to push the buckets through RCCL on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     buckets = gradient_buckets(model)
     big = [b for b in buckets if b.numel() >= 1 << 16]

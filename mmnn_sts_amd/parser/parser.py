@@ -12,6 +12,7 @@ from ..exceptions.exceptions import ConfigurationError, InitializationError
 from ..models.densenet import DenseNet121, TinyDensenet
 from ..models.mlp import MLP
 from ..models.multimodal import MultiModalModel
+from ..models.resnet import r3d_18
 
 DEFAULT_CONFIG = {
     "ImageModel": {"name": "densenet121", "modality": "t1t2", "feature_layers": 12, "num_classes": 2, "spatial_dims": 3,
@@ -61,8 +62,13 @@ class Parser:
             model = DenseNet121(**kw)
         elif name.startswith('tinydensenet'):
             model = TinyDensenet(**kw)
+        elif name.startswith('r3d_18'):
+            model = r3d_18(im['num_classes'])                       # parser/parser.py:151-152
         else:
-            raise ConfigurationError('Model name not recognized: {}\n\tThe MI355X path provides densenet121 and tinydensenet'.format(name))
+            raise ConfigurationError('Model name not recognized: {}\n\tThe MI355X path provides densenet121, tinydensenet and r3d_18'.format(name))
         if args.images and clinical:
+            # parser/parser.py:159-160,171-172: only encoders with .backbone / .features can feed the fusion model
+            assert name.startswith('tinydensenet') or name.startswith('densenet121'), \
+                "Image models used to build multimodal models must be one of 'tinydensenet' or 'densenet121'"
             model = MultiModalModel(model, self.predictors(args), im['num_classes'], im['feature_layers'], blend=getattr(args, 'blend', False))
         return model

@@ -42,3 +42,13 @@ def test_two_ranks_allreduce_equals_sequential_accumulation(tmp_path):
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k                     # both ranks hold the same reduced gradient
         err = float((r0["grads"][k].double() - g.double()).norm())
         assert err <= 2e-6 * float(g.double().norm()) + 1e-7 * gl2, (k, err, float(g.norm()))
+
+
+def test_rccl_single_rank_buckets():
+    """The RCCL ("nccl") backend itself: process group, flat 45 MB-style bucket, coalesced tail bucket, broadcast, barrier."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
