@@ -40,6 +40,7 @@ def _deps_mtime(path, seen=None):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = FLAGS + (["-DMMNN_PHASE_TRACE"] if os.environ.get("MMNN_PHASE_TRACE") == "1" else [])   # developer aid (tools/phase_trace.py)
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
     objs = []
@@ -49,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < _deps_mtime(s):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
-            jobs.append([hipcc, *FLAGS, *lang, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, *lang, "-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -214,6 +214,8 @@ static float* fptr(char* ws, size_t o) { return reinterpret_cast<float*>(ws + o)
 static void set_kz(FpropArgs& a, const Plan& p, char* ws) {
   a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
   a.kz_part_bytes = KZ_PART_BYTES; a.kz_cnt_entries = KZ_CNT_ENTRIES;
+  // developer aid: every convolution launch gets its own 64 x 16 slot of the phase-trace buffer, in launch order
+  a.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;
 }
 
 static BnFwd bnfwd(const Plan& p, StatPtr st, const float* params, float* run, long w, long b, long rm, long rv, double count, int training) {
@@ -353,6 +355,8 @@ int plan_read_timer(Plan& p, int kind, int block, double* total_ms, long* count)
 int plan_set_option(Plan& p, const char* name, long value) {
   const std::string s(name ? name : "");
   if (s == "single_stream") { p.single_stream = value != 0; return 0; }
+  if (s == "trace_buffer") { p.trace_base = reinterpret_cast<unsigned long long*>(value); p.trace_seq = 0; return 0; }   // device pointer, 0 = off
+  if (s == "trace_slots") { p.trace_slots = (int)value; return 0; }
   set_error("set_option: unknown option '%s'", s.c_str());
   return 1;
 }
@@ -375,6 +379,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
     memset(p.host_jobs, 0, p.host_jobs_bytes);
   }
   build_tables(p, params, run, ws);
+  p.trace_seq = 0;
   MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
   if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
   MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));

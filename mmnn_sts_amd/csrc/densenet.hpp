@@ -80,6 +80,7 @@ struct Plan {
   size_t timer_used = 0;
   double timer_ms[16 * MAX_BLOCKS] = {0}; long timer_count[16 * MAX_BLOCKS] = {0};   // [class][block]
   bool single_stream = false;                      // option "single_stream": backward on the caller's stream only
+  unsigned long long* trace_base = nullptr; mutable int trace_seq = 0; int trace_slots = 0;   // developer aid: per-launch phase stamps
 };
 
 enum TimerKind { T_NONE = 0, T_CONV2_FWD = 1, T_CONV2_DGRAD = 2, T_CONV2_WGRAD = 3, T_CONV1_FWD = 4, T_CONV1_DGRAD = 5,

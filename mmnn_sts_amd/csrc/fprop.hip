@@ -26,6 +26,7 @@ int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t str
   MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "fprop: non-positive extent");
   MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "fprop: volume too large for 32-bit voxel indices");
   MMNN_REQUIRE(a.in0 && a.w && a.out && a.w_ld >= a.M, "fprop: null operand or w_ld < M");
+  MMNN_REQUIRE((long)(a.M + 128) * a.D * a.H * a.W < (1l << 31), "fprop: output rows x volume too large for 32-bit element offsets");
   MMNN_REQUIRE(pro != PRO_GRAD || a.in1, "fprop: PRO_GRAD needs the normalised tensor (in1)");
   MMNN_REQUIRE((epi != EPI_MASK_STORE && epi != EPI_MASK_ACCUM) || (a.ex && a.dgamma && a.dbeta), "fprop: mask epilogue operands missing");
 #define MMNN_CASE(T, P, E) \

@@ -40,6 +40,9 @@ struct FpropArgs {
   // cross-block K-split (gridDim.z slices of the channel axis): partial tiles + per-tile arrival counters (zero on entry)
   float* kz_part; unsigned* kz_cnt;
   size_t kz_part_bytes; unsigned kz_cnt_entries;   // capacity of kz_part / kz_cnt as provided by the caller (the split is skipped when it would not fit)
+  // developer aid (tools/phase_trace.py): when non-null, thread 0 of the first 64 blocks of the launch stores shader-clock stamps
+  // of its phases to trace[block * 16 + k]; null in normal operation
+  unsigned long long* trace;
 };
 
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream);
@@ -89,6 +92,15 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   constexpr int NTHREADS = C::NTHREADS, M_B = C::M_B, V_B = C::V_B, RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+#if defined(MMNN_PHASE_TRACE)   // developer builds only (MMNN_PHASE_TRACE=1 python -m mmnn_sts_amd.build): costs ~11 registers
+  const bool tracing = a.trace != nullptr && tid == 0 && blockIdx.x < 64 && blockIdx.y == 0;
+#else
+  constexpr bool tracing = false;
+#endif
+  auto stamp = [&](int k) {
+    if (tracing) a.trace[(blockIdx.x * (gridDim.z > 1 ? 2 : 1) + (blockIdx.z ? 1 : 0)) % 64 * 16 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const bool loader = SPEC && tid >= NL;                 // wave-uniform role
   const int ltid = loader ? tid - NL : tid;              // index within the role's thread set
   const int wave = ltid >> 6;
@@ -106,7 +118,11 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // ---- which tile ----
   int n, d0 = 0, h0 = 0, w0 = 0, v0_ = 0;
   {
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx.x & 7 = XCD), each with an L2 of its own.
+    // Giving XCD x the x-th CONTIGUOUS eighth of the tile sequence makes neighbouring tiles -- which share halo rows and, for
+    // the 1x1x1 kernels, nothing -- meet in the same L2 instead of each pulling the halo from HBM / the Infinity Cache again.
     int b = blockIdx.x;
+    if (TAPS == 27 && (gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
     if (TAPS == 27) {
       const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;
       w0 = (b % nw) * TW; b /= nw;
@@ -126,37 +142,42 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   const int c_begin = (int)((long)nch_all * blockIdx.z / kz) * KC;
   const int c_end = min(a.Cin, (int)((long)nch_all * (blockIdx.z + 1) / kz) * KC);
 
-  // ---- per-channel prologue coefficients, per-row epilogue coefficients ----
-  if (PRO == PRO_BNRELU) {
-    for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
-      float ca = 0.f, cb = 0.f, mu, rs;
-      if (c < a.Cin) bn_fwd_coef(a.bn_in, c, ca, cb, mu, rs);
-      coef[c] = ca; coef[cpad + c] = cb;
-    }
-  } else if (PRO == PRO_GRAD) {
-    for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
-      float p = 0.f, q = 0.f, r = 0.f;
-      if (c < a.Cin) {
-        bn_bwd_coef(a.gr_in, c, p, q, r);
-        const float s = drop_scale(a.drop_in, n, c);
-        p *= s; q *= s; r *= s;
+  // ---- per-channel prologue coefficients, per-row epilogue coefficients.  Called AFTER the first chunk's global loads have
+  // been issued (fast path): the coefficients cost a memory round trip of their own (fp64 statistics) and are only needed when
+  // the chunk is written to LDS, so the two latencies overlap instead of adding up -- the small-extent layers are a chain of
+  // such latencies and little else. ----
+  auto prologue = [&]() {
+    if (PRO == PRO_BNRELU) {
+      for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
+        float ca = 0.f, cb = 0.f, mu, rs;
+        if (c < a.Cin) bn_fwd_coef(a.bn_in, c, ca, cb, mu, rs);
+        coef[c] = ca; coef[cpad + c] = cb;
       }
-      coef[c] = p; coef[cpad + c] = q; coef[2 * cpad + c] = r;
-    }
-  }
-  for (int m = tid; m < M_B; m += NTHREADS) {
-    float ea = 0.f, eb = 0.f, mu = 0.f, rs = 0.f, g = 0.f, ds = 1.f;
-    if (m0 + m < a.M) {
-      if (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) {
-        bn_fwd_coef(a.ebn, m0 + m, ea, eb, mu, rs);
-        g = a.ebn.gamma[m0 + m];
+    } else if (PRO == PRO_GRAD) {
+      for (int c = c_begin + tid; c < min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC); c += NTHREADS) {
+        float p = 0.f, q = 0.f, r = 0.f;
+        if (c < a.Cin) {
+          bn_bwd_coef(a.gr_in, c, p, q, r);
+          const float s = drop_scale(a.drop_in, n, c);
+          p *= s; q *= s; r *= s;
+        }
+        coef[c] = p; coef[cpad + c] = q; coef[2 * cpad + c] = r;
       }
-      if (EPI == EPI_STORE_STATS) ds = drop_scale(a.drop_out, n, m0 + m);
     }
-    ecoef[m] = ea; ecoef[M_B + m] = eb; ecoef[2 * M_B + m] = mu; ecoef[3 * M_B + m] = rs;
-    ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds;
-  }
-  __syncthreads();
+    for (int m = tid; m < M_B; m += NTHREADS) {
+      float ea = 0.f, eb = 0.f, mu = 0.f, rs = 0.f, g = 0.f, ds = 1.f;
+      if (m0 + m < a.M) {
+        if (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) {
+          bn_fwd_coef(a.ebn, m0 + m, ea, eb, mu, rs);
+          g = a.ebn.gamma[m0 + m];
+        }
+        if (EPI == EPI_STORE_STATS) ds = drop_scale(a.drop_out, n, m0 + m);
+      }
+      ecoef[m] = ea; ecoef[M_B + m] = eb; ecoef[2 * M_B + m] = mu; ecoef[3 * M_B + m] = rs;
+      ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds;
+    }
+    __syncthreads();
+  };
 
   // ---- accumulators and per-lane voxel positions ----
   f32x16 acc[MT][NT];
@@ -355,10 +376,20 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       }
     };
 
+    // Small tiles (the 16^3 .. 4^3 layers) are latency chains: issue the first chunk's loads, THEN compute the coefficients.  The
+    // big tiles of block 1 amortise the prologue over a long K loop and cannot afford the registers (staging registers live
+    // across the fp64 coefficient math: 116 -> 188 VGPRs, one register short of losing the second wave per SIMD).
+    constexpr bool EARLY = (MT * NT == 1) || (TAPS == 27 && TW <= 16);
+    if (!EARLY) prologue();
     if (SPEC) {
       // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
-      if (loader && c_begin < c_end) { load_chunk(c_begin, stA); store_chunk(c_begin, stA, 0); }
+      if (loader && c_begin < c_end) load_chunk(c_begin, stA);
+      stamp(1);
+      if (EARLY) prologue();
+      stamp(2);
+      if (loader && c_begin < c_end) store_chunk(c_begin, stA, 0);
       __syncthreads();
+      stamp(9);
       int k = 0;
       for (int c0 = c_begin; c0 < c_end; c0 += KC, ++k) {
         if (loader) {
@@ -370,9 +401,13 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       }
     } else if (PF == 1) {
       if (c_begin < c_end) load_chunk(c_begin, stA);
+      stamp(1);
+      if (EARLY) prologue();
+      stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += KC) {
         store_chunk(c0, stA);
         __syncthreads();
+        if (c0 == c_begin) stamp(9);
         if (c0 + KC < c_end) load_chunk(c0 + KC, stA);
         mfma_chunk();
         __syncthreads();
@@ -380,9 +415,13 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     } else {
       if (c_begin < c_end) load_chunk(c_begin, stA);
       if (c_begin + KC < c_end) load_chunk(c_begin + KC, stB);
+      stamp(1);
+      if (EARLY) prologue();
+      stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += 2 * KC) {
         store_chunk(c0, stA);
         __syncthreads();
+        if (c0 == c_begin) stamp(9);
         if (c0 + 2 * KC < c_end) load_chunk(c0 + 2 * KC, stA);
         mfma_chunk();
         __syncthreads();
@@ -396,6 +435,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       }
     }
   } else {
+  prologue();
   for (int c0 = c_begin; c0 < c_end; c0 += KC) {
     // ================= stage activations =================
     if (TAPS == 27) {
@@ -525,6 +565,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   }
   }
 
+  stamp(3);
   // ================= cross-group reduction of the accumulators (K-split) =================
   if (KS > 1) {
     float* rbuf = Xs;   // staging buffers are free after the last barrier
@@ -550,8 +591,13 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     }
   }
 
+  stamp(4);
   // ================= cross-block K-split: publish the partial tile; the LAST arriving slice sums all slices (in slice
-  // order: bit-reproducible) and runs the epilogue.  Placement-independent agent-scope release / acquire, no spinning. =======
+  // order: bit-reproducible) and runs the epilogue.  No spinning.  Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup
+  // visibility, "valid forms"): every partial is written with write-through (`sc1`) stores, drained with vmcnt(0) before the
+  // workgroup's agent-scope ticket; the last arriver reads the partials with `sc1` loads, which bypass its own XCD's L2.  An
+  // agent-scope release fence instead writes back the XCD's whole dirty L2 -- 3-6 us per kernel in the phase trace, as long as
+  // the K loop of the 8^3 / 4^3 layers itself. =======
   if (kz > 1) {
     constexpr int NSLOT = WM * WN * MT * NT;
     const long tile_id = blockIdx.x + (long)gridDim.x * blockIdx.y;
@@ -563,25 +609,19 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) part[(((long)blockIdx.z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(part + (((long)blockIdx.z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane, acc[i][j][r], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* ticket = reinterpret_cast<unsigned*>(ecoef + C::ECOEF * M_B);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    stamp(5);
     const unsigned arrived = *ticket;
     if (arrived != (unsigned)(kz - 1)) return;            // not the last slice of this tile: done
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     if (kg == 0 && !loader) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -591,11 +631,14 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
           for (int z = 0; z < kz; ++z)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += part[(((long)z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += __hip_atomic_load(part + (((long)z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
   }
 
+  stamp(6);
   // ================= epilogue =================
   float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
   float* red1 = red0 + WN * M_B;
@@ -603,7 +646,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   const float* exn = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) ? a.ex + (long)n * a.ex_ns + (long)a.ex_coff * V : nullptr;
   const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
 
-  long vox[NT];
+  int vox[NT];
   bool vok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -612,7 +655,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
       const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
       vok[j] = d < a.D && h < a.H && w < a.W;
-      vox[j] = ((long)d * a.H + h) * a.W + w;
+      vox[j] = (d * a.H + h) * a.W + w;
     } else {
       vox[j] = v0_ + t;
       vok[j] = vox[j] < V;
@@ -623,40 +666,65 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float s0[16], s1[16];
+    // The mask epilogues read one (ex) or two (ex, out) tensors per element.  All of a tile row's loads are issued BEFORE its first
+    // store: `out` may alias `ex` as far as the compiler knows, so a load placed after a store is never hoisted above it and every
+    // accumulator row would pay a full memory round trip of its own (phase trace r02: 34 us of a 126 us block in block 1's data gradient).
+    // Rows are processed in batches of RB (register budget: the big tiles of block 1 must stay at two waves per SIMD).  Element
+    // offsets are 32-bit (host check: M * V < 2^31), so an address costs one register beside the uniform base pointer.
+    constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
+    constexpr int RB = (MT * NT >= 4) ? 8 : 16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = wm * MT * 32 + i * 32 + acc_row(r, half);
-      const bool mok = (m0 + ml) < a.M;
-      float t0 = 0.f, t1 = 0.f;
+    for (int rb = 0; rb < 16; rb += RB) {
+      float xe[MASK ? RB : 1][NT], go[(EPI == EPI_MASK_ACCUM) ? RB : 1][NT];
+      if (MASK) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const bool ok = mok && vok[j];
-        const long o = (long)(m0 + ml) * V + vox[j];
-        float val = acc[i][j][r];
-        if (EPI == EPI_STORE) {
-          if (ok) outn[o] = val;
-        } else if (EPI == EPI_STORE_STATS) {
-          val *= ecoef[5 * M_B + ml];
-          if (ok) {
-            outn[o] = val;
-            t0 += val;
-            t1 += val * val;
-          }
-        } else {
-          if (ok) {
-            const float x = exn[o];
-            const float pre = fmaf(ecoef[ml], x, ecoef[M_B + ml]);
-            const float z = pre > 0.f ? val : 0.f;
-            const float xh = (x - ecoef[2 * M_B + ml]) * ecoef[3 * M_B + ml];
-            t0 += z;
-            t1 += z * xh;
-            if (EPI == EPI_MASK_STORE) outn[o] = z;
-            else outn[o] += ecoef[4 * M_B + ml] * z;
+        for (int q = 0; q < RB; ++q) {
+          const int ml = wm * MT * 32 + i * 32 + acc_row(rb + q, half);
+          const bool mok = (m0 + ml) < a.M;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;   // unconditional loads (clamped)
+            xe[MASK ? q : 0][j] = exn[o];
+            if (EPI == EPI_MASK_ACCUM) go[(EPI == EPI_MASK_ACCUM) ? q : 0][j] = outn[o];
           }
         }
       }
-      s0[r] = t0;
-      s1[r] = t1;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q;
+        const int ml = wm * MT * 32 + i * 32 + acc_row(r, half);
+        const bool mok = (m0 + ml) < a.M;
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bool ok = mok && vok[j];
+          const unsigned o = (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j];
+          float val = acc[i][j][r];
+          if (EPI == EPI_STORE) {
+            if (ok) outn[o] = val;
+          } else if (EPI == EPI_STORE_STATS) {
+            val *= ecoef[5 * M_B + ml];
+            if (ok) {
+              outn[o] = val;
+              t0 += val;
+              t1 += val * val;
+            }
+          } else {
+            if (ok) {
+              const float x = xe[MASK ? q : 0][j];
+              const float pre = fmaf(ecoef[ml], x, ecoef[M_B + ml]);
+              const float z = pre > 0.f ? val : 0.f;
+              const float xh = (x - ecoef[2 * M_B + ml]) * ecoef[3 * M_B + ml];
+              t0 += z;
+              t1 += z * xh;
+              if (EPI == EPI_MASK_STORE) outn[o] = z;
+              else outn[o] = go[(EPI == EPI_MASK_ACCUM) ? q : 0][j] + ecoef[4 * M_B + ml] * z;
+            }
+          }
+        }
+        s0[r] = t0;
+        s1[r] = t1;
+      }
     }
     if (want_sums) {
       const float r0 = half_reduce16(s0, lane);
@@ -669,6 +737,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     }
   }
   }
+  stamp(7);
   if (want_sums) {
     __syncthreads();
     for (int m = tid; m < M_B; m += NTHREADS) {
@@ -689,6 +758,12 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         }
       }
     }
+  }
+  stamp(8);
+  if (tracing) {
+    a.trace[10] = ((unsigned long long)TAPS << 48) | ((unsigned long long)PRO << 40) | ((unsigned long long)EPI << 32) | ((unsigned long long)a.M << 16) | (unsigned long long)a.Cin;
+    a.trace[11] = ((unsigned long long)gridDim.x << 32) | ((unsigned long long)gridDim.y << 16) | gridDim.z;
+    a.trace[12] = ((unsigned long long)(WM * WN * KS) << 32) | ((unsigned long long)KC << 16) | (unsigned long long)(MT * NT);
   }
 }
 

@@ -62,13 +62,10 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
     if (blocks_b >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 2, 1, 1, 64, 1, 1, 64>(a, s);
     return launch_cfg<1, PRO, EPI, 1, 1, 8, 1, 1, 128, 1, 1, 32>(a, s);   // few voxels: deep K chunks (the K loop is latency-bound)
   } else {
-  static const int exp_tile = [] { const char* e = getenv("MMNN_EXP_TILE27"); return e ? atoi(e) : 0; }();   // tile experiments
   if (a.M <= 32) {
-    if (a.W > 16) {
-      if (exp_tile == 11) return launch_cfg<27, PRO, EPI, 1, 4, 2, 1, 2, 8, 2, 4, 32>(a, s);          // 8 compute waves, in-block K-split
-      if (exp_tile == 12) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 1, 8, 1, 4, 32, true>(a, s);    // 128-voxel tiles: 2 blocks per CU
-      return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>(a, s);
-    }
+    // Tried and measured no better at 32^3 (r02, tools/exp_classes.py): 8 compute waves with an in-block K-split instead of
+    // loader waves (141 vs 140 us), 128-voxel tiles for two blocks per CU (172 us).
+    if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>(a, s);
     if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 2, 4, 1, 1, 16, 1, 4, 16>(a, s);
     if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);
@@ -76,9 +73,8 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
   if (a.W > 16) {
     // KC = 2: the smallest chunk (one MFMA k-pair per tap) keeps the LDS footprint low enough for 3-4 blocks per CU, which
     // hides the staging latency better than loader waves or KC = 4 do here (194 -> 173 us at block 1).
-    if (exp_tile == 21) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 1, 2, 1, 2, 32>(a, s);            // 64-voxel tiles: 4 blocks per CU
-    if (exp_tile == 22) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 2, 4, 1, 4, 32>(a, s);            // 8 waves, in-block K-split, KC = 4
-    if (exp_tile == 23) return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32, true>(a, s);      // loader waves
+    // Tried and measured slower for the data gradient at 32^3 (r02): 64-voxel tiles / 4 blocks per CU (180 us, register
+    // allocation still caps the CU at 3 waves per SIMD), 8 waves with an in-block K-split and KC = 4 (231 us), loader waves (213 us).
     return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
   }
   if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);

@@ -110,14 +110,18 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
   const int ntiles = a.N * tiles_per_n;
   const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
 
-  if (tid < 32) {
-    float ca = 0.f, cb = 0.f, mu, rs;
-    if (PRO_X == PRO_BNRELU && c0 + tid < a.Cin) bn_fwd_coef(a.bn, c0 + tid, ca, cb, mu, rs);
-    xcoef[tid] = ca; xcoef[32 + tid] = cb;
-    float p = 0.f, q = 0.f, r = 0.f;
-    if (tid < a.M) bn_bwd_coef(a.gr, tid, p, q, r);
-    gbase[tid] = p; gbase[32 + tid] = q; gbase[64 + tid] = r;
-  }
+  // BN coefficients of both operands (one memory round trip over the fp64 statistics).  In the fast path they are computed
+  // AFTER the first tile's loads were issued, so the two latencies overlap.
+  auto coefficients = [&]() {
+    if (tid < 32) {
+      float ca = 0.f, cb = 0.f, mu, rs;
+      if (PRO_X == PRO_BNRELU && c0 + tid < a.Cin) bn_fwd_coef(a.bn, c0 + tid, ca, cb, mu, rs);
+      xcoef[tid] = ca; xcoef[32 + tid] = cb;
+      float p = 0.f, q = 0.f, r = 0.f;
+      if (tid < a.M) bn_bwd_coef(a.gr, tid, p, q, r);
+      gbase[tid] = p; gbase[32 + tid] = q; gbase[64 + tid] = r;
+    }
+  };
   const int tap0 = (wave < 5) ? wave * 3 : 15 + (wave - 5) * 4;       // first tap of this wave
   const int ntap = (wave < 5) ? 3 : 4;
   // lane-half offset: voxel (s + 32*half) = voxel s shifted by 32/TW rows
@@ -251,6 +255,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
     };
     int cur_n = -1;
     if (t_begin < t_end) load_tile(t_begin);
+    coefficients();
     for (int tile = t_begin; tile < t_end; ++tile) {
       int n, d0, h0, w0;
       tile_origin(tile, n, d0, h0, w0);
@@ -269,6 +274,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
       __syncthreads();
     }
   } else {
+  coefficients();
   int cur_n = -1;
   for (int tile = t_begin; tile < t_end; ++tile) {
     int b = tile;
@@ -377,16 +383,18 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
   const int nchunks = a.N * chunks_per_n;
   const int k_begin = (int)((long)nchunks * split / a.nsplit), k_end = (int)((long)nchunks * (split + 1) / a.nsplit);
 
-  for (int c = tid; c < CB; c += NTHREADS) {
-    float ca = 0.f, cb = 0.f, mu, rs;
-    if (PRO_X == PRO_BNRELU && c0 + c < a.Cin) bn_fwd_coef(a.bn, c0 + c, ca, cb, mu, rs);
-    xcoef[c] = ca; xcoef[CB + c] = cb;
-  }
-  for (int m = tid; m < 128; m += NTHREADS) {
-    float p = 0.f, q = 0.f, r = 0.f;
-    if (m0 + m < a.M) bn_bwd_coef(a.gr, m0 + m, p, q, r);
-    gbase[m] = p; gbase[128 + m] = q; gbase[256 + m] = r;
-  }
+  auto coefficients = [&]() {   // see wgrad3_body: computed after the first chunk's loads were issued (fast path)
+    for (int c = tid; c < CB; c += NTHREADS) {
+      float ca = 0.f, cb = 0.f, mu, rs;
+      if (PRO_X == PRO_BNRELU && c0 + c < a.Cin) bn_fwd_coef(a.bn, c0 + c, ca, cb, mu, rs);
+      xcoef[c] = ca; xcoef[CB + c] = cb;
+    }
+    for (int m = tid; m < 128; m += NTHREADS) {
+      float p = 0.f, q = 0.f, r = 0.f;
+      if (m0 + m < a.M) bn_bwd_coef(a.gr, m0 + m, p, q, r);
+      gbase[m] = p; gbase[128 + m] = q; gbase[256 + m] = r;
+    }
+  };
   f32x16 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -481,6 +489,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
     };
     int cur_n = -1;
     if (k_begin < k_end) load_chunk(k_begin);
+    coefficients();
     for (int ch = k_begin; ch < k_end; ++ch) {
       const int n = ch / chunks_per_n;
       if (n != cur_n) {
@@ -498,6 +507,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
       __syncthreads();
     }
   } else {
+  coefficients();
   int cur_n = -1;
   for (int ch = k_begin; ch < k_end; ++ch) {
     const int n = ch / chunks_per_n;
