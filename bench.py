@@ -311,7 +311,7 @@ def main():
                                "ms_per_step": top["ms_per_step"], "step_frac": res["step_fp32_frac_of_peak"],
                                "timing": "HIP events on the launch stream, 4 untimed steps after the timed region, backward on one stream",
                                "conv_ms_per_step": sum(r["ms_per_step"] for r in rows),
-                               "classes": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"} for r in rows[:12]]}
+                               "classes": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"} for r in rows]}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.micro_batch, a.size)
         print(json.dumps(res), flush=True)

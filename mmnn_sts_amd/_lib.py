@@ -5,7 +5,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmnn_sts.so")
+LIB_PATH = os.environ.get("MMNN_LIB_PATH") or os.path.join(_HERE, "libmmnn_sts.so")   # override: developer builds only
 _lib = None
 
 

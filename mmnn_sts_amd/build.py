@@ -40,7 +40,10 @@ def _deps_mtime(path, seen=None):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = FLAGS + (["-DMMNN_PHASE_TRACE"] if os.environ.get("MMNN_PHASE_TRACE") == "1" else [])   # developer aid (tools/phase_trace.py)
+    trace = os.environ.get("MMNN_PHASE_TRACE") == "1"     # developer build (tools/phase_trace.py): its own objects and library
+    flags = FLAGS + (["-DMMNN_PHASE_TRACE"] if trace else [])
+    OBJ = os.path.join(HERE, "build_trace" if trace else "build")
+    LIB = os.path.join(HERE, "libmmnn_sts_trace.so" if trace else "libmmnn_sts.so")
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
     objs = []

@@ -423,6 +423,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       a.out = fptr(ws, p.o_t1[b][l]); a.out_ns = (long)p.mid * p.Vb[b]; a.out_coff = 0;
       a.st_out = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
       if (!training) a.st_out.sum = nullptr;
+      a.pf_ptr = fptr(ws, p.o_pk_c2f[b][l]); a.pf_bytes = (unsigned)(sizeof(float) * c.growth * p.mid * 27);
       { ScopedTimer t(p, T_CONV1_FWD, b, stream); rc = launch_fprop(a, 1, PRO_BNRELU, EPI_STORE_STATS, stream); }
       if (rc) return rc;
       // conv2: ReLU(BN(T1)) -> growth new channels of the concat buffer (+ channel dropout)
@@ -438,6 +439,11 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       e.drop_out = dropcfg(p, seed, layer_id, training);
       e.st_out = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);
       if (!training) e.st_out.sum = nullptr;
+      if (l + 1 < c.block_layers[b]) {
+        e.pf_ptr = fptr(ws, p.o_pk_c1[b][l + 1]); e.pf_bytes = (unsigned)(sizeof(float) * p.mid * p.layers[b][l + 1].cin);
+      } else if (b != nb - 1) {
+        e.pf_ptr = fptr(ws, p.o_pk_tr[b]); e.pf_bytes = (unsigned)(sizeof(float) * p.trans[b].cin * p.trans[b].cout);
+      }
       { ScopedTimer t(p, T_CONV2_FWD, b, stream); rc = launch_fprop(e, 27, PRO_BNRELU, EPI_STORE_STATS, stream); }
       if (rc) return rc;
     }
@@ -459,6 +465,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       a.out = fptr(ws, p.o_x[b + 1]); a.out_ns = (long)p.ctot_b[b + 1] * p.Vb[b + 1]; a.out_coff = 0;
       a.st_out = statptr(ws, p.o_st_x[b + 1], p.ctot_b[b + 1], 0);
       if (!training) a.st_out.sum = nullptr;
+      a.pf_ptr = fptr(ws, p.o_pk_c1[b + 1][0]); a.pf_bytes = (unsigned)(sizeof(float) * p.mid * p.layers[b + 1][0].cin);
       if ((rc = launch_fprop(a, 1, PRO_NONE, EPI_STORE_STATS, stream))) return rc;
     } else {
       BnApplyArgs q;
@@ -691,6 +698,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       a.ex = fptr(ws, p.o_t1[b][l]); a.ex_ns = tns; a.ex_coff = 0;
       a.ebn = bn2;
       a.dbeta = dg2.sum; a.dgamma = dg2.sq;
+      a.pf_ptr = params + lo.c1; a.pf_bytes = (unsigned)(sizeof(float) * p.mid * lo.cin);
       { ScopedTimer t(p, T_CONV2_DGRAD, b, stream); rc = launch_fprop(a, 27, PRO_GRAD, EPI_MASK_STORE, stream); }
       if (rc) return rc;
       WgradArgs w2, w1;
@@ -717,6 +725,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       d.ebn = bn1;
       d.dbeta = dg1.sum; d.dgamma = dg1.sq;
       d.s_acc = sptr(b, 0);
+      if (l > 0) { d.pf_ptr = fptr(ws, p.o_pk_c2b[b][l - 1]); d.pf_bytes = (unsigned)(sizeof(float) * c.growth * p.mid * 27); }
       { ScopedTimer t(p, T_CONV1_DGRAD, b, stream); rc = launch_fprop(d, 1, PRO_GRAD, EPI_MASK_ACCUM, stream); }
       if (rc) return rc;
       // both weight gradients of this layer can run from here on (its G slice was final before conv2 dgrad, dZ2 and

@@ -16,4 +16,9 @@ for spec in sys.argv[1:]:
     d = json.loads(r.stdout.strip().splitlines()[-1])
     cls = {c["class"]: c for c in d["roofline"]["classes"]}
     pick = ["conv2_fwd.b1", "conv2_dgrad.b1", "conv2_wgrad.b1", "conv2_fwd.b2", "conv2_dgrad.b2", "conv1_dgrad.b1", "stem_conv", "stem_wgrad"]
+    if os.environ.get("ALL_CLASSES") == "1":
+        print(f"{spec}: {d['ms_per_step']:.3f} ms/step, conv kernels {d['roofline']['conv_ms_per_step']:.3f} ms/step (single stream)")
+        for c in d["roofline"]["classes"]:
+            print(f"   {c['class']:16s} {c['ms_per_step']:.3f} ms  {c['launches'] // 4:3d}x {c['avg_us']:7.1f} us  {c['frac']:.3f} of peak")
+        continue
     print(f"{spec:40s} {d['ms_per_step']:.3f} ms/step  " + "  ".join(f"{k}={cls[k]['avg_us']:.1f}us/{cls[k]['frac']:.2f}" for k in pick if k in cls), flush=True)
