@@ -703,6 +703,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       if (rc) return rc;
       WgradArgs w2, w1;
       layer_wgrad_args(p, params, run, ws, b, l, layer_id, seed, w2, w1);
+      w2.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;   // developer aid
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);

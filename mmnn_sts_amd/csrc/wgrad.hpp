@@ -31,6 +31,7 @@ struct WgradArgs {
   BnFwd bn;                                   // PRO_BNRELU (ignored for PRO_NONE)
   // output slabs: 1x1: slab[split][m][c]   3x3x3: slab[split][tap][m][c]
   float* slab; long slab_stride; int nsplit;
+  unsigned long long* trace;   // developer builds (MMNN_PHASE_TRACE): per-block phase cycle sums; null otherwise
 };
 
 int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream);
@@ -254,8 +255,16 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
       }
     };
     int cur_n = -1;
+#if defined(MMNN_PHASE_TRACE)
+    const bool tracing = a.trace != nullptr && tid == 0 && split < 16 && cg == 0;
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = tracing ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr[k] += t - tprev; tprev = t; } };
+#else
+    auto lap = [&](int) {};
+#endif
     if (t_begin < t_end) load_tile(t_begin);
     coefficients();
+    lap(0);
     for (int tile = t_begin; tile < t_end; ++tile) {
       int n, d0, h0, w0;
       tile_origin(tile, n, d0, h0, w0);
@@ -268,11 +277,24 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
         __syncthreads();
       }
       store_tile(tile);
+      lap(1);
       __syncthreads();
+      lap(2);
       if (tile + 1 < t_end) load_tile(tile + 1);
+      lap(3);
       mfma_tile();
+      lap(4);
       __syncthreads();
+      lap(5);
     }
+#if defined(MMNN_PHASE_TRACE)
+    if (tracing) {
+      for (int k = 0; k < 6; ++k) a.trace[split * 16 + k] = tr[k];
+      a.trace[split * 16 + 6] = (unsigned long long)(t_end - t_begin);
+      a.trace[10] = (27ull << 48) | (9ull << 40) | ((unsigned long long)a.M << 16) | (unsigned long long)a.Cin;
+      a.trace[11] = ((unsigned long long)gridDim.x << 32) | ((unsigned long long)gridDim.y << 16) | gridDim.z;
+    }
+#endif
   } else {
   coefficients();
   int cur_n = -1;

@@ -15,7 +15,7 @@ for spec in sys.argv[1:]:
         continue
     d = json.loads(r.stdout.strip().splitlines()[-1])
     cls = {c["class"]: c for c in d["roofline"]["classes"]}
-    pick = ["conv2_fwd.b1", "conv2_dgrad.b1", "conv2_wgrad.b1", "conv2_fwd.b2", "conv2_dgrad.b2", "conv1_dgrad.b1", "stem_conv", "stem_wgrad"]
+    pick = os.environ.get("PICK", "conv2_fwd.b1,conv2_dgrad.b1,conv2_wgrad.b1,conv2_fwd.b2,conv2_dgrad.b2,conv1_dgrad.b1,stem_conv,stem_wgrad").split(",")
     if os.environ.get("ALL_CLASSES") == "1":
         print(f"{spec}: {d['ms_per_step']:.3f} ms/step, conv kernels {d['roofline']['conv_ms_per_step']:.3f} ms/step (single stream)")
         for c in d["roofline"]["classes"]:

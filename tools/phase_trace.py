@@ -38,6 +38,13 @@ for i in range(SLOTS):
     taps, pro, epi, M, cin = tag >> 48, (tag >> 40) & 255, (tag >> 32) & 255, (tag >> 16) & 0xFFFF, tag & 0xFFFF
     g = int(t[i, 0, 11]); gx, gy, gz = g >> 32, (g >> 16) & 0xFFFF, g & 0xFFFF
     w = int(t[i, 0, 12]); waves, kc = w >> 32, (w >> 16) & 0xFFFF
+    if pro == 9:      # wgrad3: per-block cycle SUMS over the block's tiles
+        blk = np.array([[int(t[i, b, k]) for k in range(7)] for b in range(16) if int(t[i, b, 6]) > 0], dtype=np.float64)
+        if len(blk):
+            m = np.median(blk, axis=0)
+            print(f"{i:3d}  wgrad3 M {M} Cin {cin} grid {gx},{gy},{gz}: tiles/block {m[6]:.0f} | first load+coef {m[0]:.0f} | per tile: store {m[1] / m[6]:.0f}  "
+                  f"barrier {m[2] / m[6]:.0f}  load issue {m[3] / m[6]:.0f}  mfma {m[4] / m[6]:.0f}  barrier {m[5] / m[6]:.0f}  = {(m[1:6].sum()) / m[6]:.0f} cycles")
+        continue
     rows = []
     for b in range(64):
         st = t[i, b]
