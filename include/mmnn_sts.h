@@ -76,7 +76,9 @@ int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
 int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches);
 /* plan options.  "single_stream" (0/1): run the whole backward on the caller's stream instead of overlapping the weight-gradient
- * kernels on two side streams -- same results, un-overlapped kernel durations for profiling. */
+ * kernels on two side streams -- same results, un-overlapped kernel durations for profiling.  "params_version" (any non-zero
+ * number the caller changes whenever it changed a parameter; 0 = unknown, the default): the forward re-packs the weights only
+ * when the version, the parameter buffer or the workspace differs from the last packed one. */
 int mmnn_densenet_set_option(void* plan, const char* name, int64_t value);
 /* byte offset of a named workspace region (tests / GradCAM): "x","g","t1","conv0","st_x",... ; -1 if unknown */
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j);

@@ -188,6 +188,9 @@ def train_survival(model, train_ds, val_ds, args, device, rank, world):
     val_loader = torch.utils.data.DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, collate_fn=collate, drop_last=len(val_ds) > args.batch_size)
     model = model.to(device)
     D.broadcast_parameters(model)
+    for m in model.modules():                 # this loop only changes weights through FusedSGD: repack them once per optimizer step,
+        if hasattr(m, "repack_policy"):       # not on each of the 64 / batch micro-batch forwards in between
+            m.repack_policy = "versioned"
     interval = super_batch_interval(args.batch_size, world)
     steps_per_epoch = optimizer_steps_per_epoch(len(loader), interval)
     opt = FusedSGD(model, lr=args.lr, momentum=args.momentum, nesterov=True, weight_decay=args.weight_decay)

@@ -167,79 +167,94 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
     f32x4 xv[XV_IT], y0[Y_IT], y1[Y_IT];
     float xh[XH_IT];
     unsigned okv = 0, okh = 0, oky = 0;
-    auto row_info = [&](int r, int d0, int h0, int& cl, int& lrow, long& gro, bool& rowok) {
-      const int hy = r % HS, dz = (r / HS) % DS;
-      cl = r / (HS * DS);
-      const int d = d0 + dz - 1, h = h0 + hy - 1;
-      rowok = (c0 + cl < a.Cin) && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H;
-      gro = (long)cl * V + ((long)d * a.H + h) * a.W;
-      lrow = cl * XS + (dz * HS + hy) * RS;
-    };
+    // Per-item descriptors that do not depend on the tile, computed ONCE per block: global offset relative to the tile origin,
+    // LDS destination, local channel and the (dz, hy) the bounds checks need.  Per tile an item then costs one add and four
+    // compares instead of a dozen divisions by constants and 64-bit multiplies -- the staging arithmetic of both waves of a SIMD
+    // was 4.4k of the 19.9k cycles a tile takes (phase trace r02), and it delays the partner wave's MFMAs (VALU issue is shared).
+    int xv_s[XV_IT], xv_l[XV_IT], xv_k[XV_IT];      // k packs cl | dz << 8 | hy << 16 | (4 * q) << 24, or -1 for "never valid"
+    int xh_s[XH_IT], xh_l[XH_IT], xh_k[XH_IT];
+    int y_s[Y_IT], y_k[Y_IT];                       // y_k packs m | dz << 8 | hy << 16 | wx << 24
+#pragma unroll
+    for (int i = 0; i < XV_IT; ++i) {
+      const int it = tid + i * NTHREADS, r = it / VPR, q4 = 4 * (it % VPR);
+      const int hy = r % HS, dz = (r / HS) % DS, cl = r / (HS * DS);
+      const bool ok = (it < XV_ITEMS) && (c0 + cl < a.Cin);
+      xv_s[i] = cl * V + (dz * a.H + hy) * a.W + q4;
+      xv_l[i] = cl * XS + (dz * HS + hy) * RS + 1 + q4;
+      xv_k[i] = ok ? (cl | (dz << 8) | (hy << 16) | (q4 << 24)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XH_IT; ++i) {
+      const int it = tid + i * NTHREADS, r = it >> 1, side = it & 1;
+      const int hy = r % HS, dz = (r / HS) % DS, cl = r / (HS * DS);
+      const bool ok = (it < XH_ITEMS) && (c0 + cl < a.Cin);
+      xh_s[i] = cl * V + (dz * a.H + hy) * a.W + (side ? TW : -1);
+      xh_l[i] = cl * XS + (dz * HS + hy) * RS + (side ? TW + 1 : 0);
+      xh_k[i] = ok ? (cl | (dz << 8) | (hy << 16) | (side << 24)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int it = tid + i * NTHREADS, m = it >> 4, t = 4 * (it & 15);
+      const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+      const bool ok = (it < Y_ITEMS) && m < a.M;
+      y_s[i] = m * V + (dz * a.H + hy) * a.W + wx;
+      y_k[i] = ok ? (m | (dz << 8) | (hy << 16) | (wx << 24)) : -1;
+    }
     auto load_tile = [&](int tile) {
       int n, d0, h0, w0;
       tile_origin(tile, n, d0, h0, w0);
       const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
       const float* g0n = a.g0 + (long)n * a.g0_ns + (long)a.g0_coff * V;
       const float* g1n = a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
+      const int xbase = ((d0 - 1) * a.H + (h0 - 1)) * a.W + w0;      // tile origin of the halo box (may be negative: only used when in range)
+      const int ybase = (d0 * a.H + h0) * a.W + w0;
       okv = okh = oky = 0;
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        int cl, lrow; long gro; bool rowok;
-        row_info(it / VPR, d0, h0, cl, lrow, gro, rowok);
-        const int w = w0 + 4 * (it % VPR);
-        const bool ok = (it < XV_ITEMS) && rowok && w < a.W;
+        const int k = xv_k[i];
+        const int d = d0 - 1 + ((k >> 8) & 255), h = h0 - 1 + ((k >> 16) & 255), w = w0 + ((k >> 24) & 255);
+        const bool ok = k >= 0 && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && w < a.W;
         okv |= (ok ? 1u : 0u) << i;
-        xv[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? gro + w : 0));
+        xv[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? xv_s[i] + xbase : 0));
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        int cl, lrow; long gro; bool rowok;
-        row_info(it >> 1, d0, h0, cl, lrow, gro, rowok);
-        const int w = (it & 1) ? w0 + TW : w0 - 1;
-        const bool ok = (it < XH_ITEMS) && rowok && (unsigned)w < (unsigned)a.W;
+        const int k = xh_k[i];
+        const int d = d0 - 1 + ((k >> 8) & 255), h = h0 - 1 + ((k >> 16) & 255), w = ((k >> 24) & 1) ? w0 + TW : w0 - 1;
+        const bool ok = k >= 0 && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
         okh |= (ok ? 1u : 0u) << i;
-        xh[i] = xn[ok ? gro + w : 0];
+        xh[i] = xn[ok ? xh_s[i] + xbase : 0];
       }
 #pragma unroll
       for (int i = 0; i < Y_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        const int m = it >> 4, t = 4 * (it & 15);
-        const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
-        const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
-        const bool ok = (it < Y_ITEMS) && m < a.M && d < a.D && h < a.H && w < a.W;
-        const long g = ok ? (long)m * V + ((long)d * a.H + h) * a.W + w : 0;
+        const int k = y_k[i];
+        const int d = d0 + ((k >> 8) & 255), h = h0 + ((k >> 16) & 255), w = w0 + ((k >> 24) & 255);
+        const bool ok = k >= 0 && d < a.D && h < a.H && w < a.W;
+        const int g = ok ? y_s[i] + ybase : 0;
         oky |= (ok ? 1u : 0u) << i;
         y0[i] = *reinterpret_cast<const f32x4*>(g0n + g);
         y1[i] = *reinterpret_cast<const f32x4*>(g1n + g);
       }
     };
-    auto store_tile = [&](int tile) {
-      int n, d0, h0, w0;
-      tile_origin(tile, n, d0, h0, w0);
+    auto store_tile = [&](int) {
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        if (it < XV_ITEMS) {
-          int cl, lrow; long gro; bool rowok;
-          row_info(it / VPR, d0, h0, cl, lrow, gro, rowok);
+        if (tid + i * NTHREADS < XV_ITEMS) {
+          const int cl = xv_k[i] & 255;
           const bool ok = (okv >> i) & 1u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xv[i][e], xcoef[32 + cl]), 0.f) : xv[i][e];
-            Xs[lrow + 1 + 4 * (it % VPR) + e] = ok ? o : 0.f;
+            Xs[xv_l[i] + e] = ok ? o : 0.f;
           }
         }
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
-        const int it = tid + i * NTHREADS;
-        if (it < XH_ITEMS) {
-          int cl, lrow; long gro; bool rowok;
-          row_info(it >> 1, d0, h0, cl, lrow, gro, rowok);
+        if (tid + i * NTHREADS < XH_ITEMS) {
+          const int cl = xh_k[i] & 255;
           const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xh[i], xcoef[32 + cl]), 0.f) : xh[i];
-          Xs[lrow + ((it & 1) ? TW + 1 : 0)] = ((okh >> i) & 1u) ? o : 0.f;
+          Xs[xh_l[i]] = ((okh >> i) & 1u) ? o : 0.f;
         }
       }
 #pragma unroll

@@ -73,7 +73,13 @@ class _Backbone(nn.Sequential):
 
     # ---- native state: flat buffers + launch plans.  Owned by exactly ONE module object -------------------------------
     _NATIVE_STATE = ("_flat", "_flat_run", "_flat_nbt", "_flat_grad", "_plans", "_anchor", "_params", "_bns", "_fwd_token",
-                     "_grads_attached", "_grads_stale")
+                     "_grads_attached", "_grads_stale", "_explicit_version")
+
+    #: "always": the weights are re-packed for the kernels on every forward (safe with any way of writing parameters).
+    #: "versioned": re-pack only when a parameter changed, as told by the autograd version counters of the parameters (every
+    #: in-place op on a Parameter, `load_state_dict`, torch optimizers) plus `mark_params_changed()` (called by FusedSGD and by
+    #: re-flattening).  Writes through `p.data` are invisible to version counters: call `mark_params_changed()` after them.
+    repack_policy = "always"
 
     def _reset_native_state(self) -> None:
         """Non-module state (kept out of state_dict): nothing flattened, no plan.  Rebuilt lazily by the next forward."""
@@ -88,6 +94,17 @@ class _Backbone(nn.Sequential):
         object.__setattr__(self, "_fwd_token", 0)
         object.__setattr__(self, "_grads_attached", False)
         object.__setattr__(self, "_grads_stale", True)
+        object.__setattr__(self, "_explicit_version", 1)
+
+    def mark_params_changed(self) -> None:
+        """Tell the backbone that parameter values were written behind autograd's back (raw pointers, `p.data`)."""
+        object.__setattr__(self, "_explicit_version", self._explicit_version + 1)
+
+    def _params_version(self) -> int:
+        v = self._explicit_version * 1000003 + self._flat._version * 7919
+        for p in self._params:
+            v += p._version
+        return (v % ((1 << 62) - 1)) + 1          # non-zero
 
     def __getstate__(self):
         """copy.deepcopy(model) / torch.save(model) copy the module WITHOUT its native plan handles (raw pointers: two owners
@@ -135,6 +152,7 @@ class _Backbone(nn.Sequential):
         object.__setattr__(self, "_grads_attached", False)
         object.__setattr__(self, "_grads_stale", True)
         object.__setattr__(self, "_anchor", torch.zeros(1, device=dev, requires_grad=True))
+        self.mark_params_changed()
         for p in params:
             p.grad = None
 
@@ -227,6 +245,10 @@ class _Backbone(nn.Sequential):
         ent = self._plan_for(x)
         out = torch.empty(ent["out_shape"], dtype=torch.float32, device=x.device)
         seed = ops.next_seed()
+        version = self._params_version() if self.repack_policy == "versioned" else 0
+        if version != ent.get("version", 0):
+            _lib.check(_lib.lib().mmnn_densenet_set_option(ent["plan"], b"params_version", version), "set_option")
+            ent["version"] = version
         _lib.check(_lib.lib().mmnn_densenet_forward(ent["plan"], self._flat.data_ptr(), self._flat_run.data_ptr(), x.data_ptr(),
                                                     ent["ws"].data_ptr(), out.data_ptr(), int(training), seed,
                                                     torch.cuda.current_stream().cuda_stream), "mmnn_densenet_forward")

@@ -36,6 +36,7 @@ class FusedSGD(torch.optim.Optimizer):
                 self._bufs[id(bb)] = torch.empty_like(flat)
             _lib.check(_lib.lib().mmnn_sgd_step(flat.data_ptr(), grad.data_ptr(), self._bufs[id(bb)].data_ptr(), flat.numel(), lr, mom, wd,
                                                 nes, int(first), st), "sgd_step")
+            bb.mark_params_changed()          # written through the raw pointer: invisible to autograd's version counters
         ps = [p for p in self._rest if p.grad is not None]
         if ps:
             gs = [p.grad for p in ps]

@@ -93,3 +93,46 @@ def test_state_dict_round_trip_and_device_moves():
     with torch.no_grad():
         assert torch.equal(m2(x), y0)
     assert m2.backbone._storage_ok(full=True)
+
+
+def test_versioned_weight_repack():
+    """`repack_policy = "versioned"`: the weight panels are re-packed only after a parameter changed (in-place op on a Parameter,
+    load_state_dict, FusedSGD), never spuriously skipped; "always" (default) repacks on every forward."""
+    from mmnn_sts_amd import _lib
+    from mmnn_sts_amd.models.densenet import DenseNet
+    from mmnn_sts_amd.optim import FusedSGD
+    torch.manual_seed(5)
+    m = DenseNet(spatial_dims=3, in_channels=1, out_channels=2, feature_channels=12, block_config=(2, 2), dropout_prob=0.0).to("cuda")
+    bb = m.backbone
+    x = torch.randn(2, 1, 32, 32, 32, device="cuda")
+    packs = lambda: _lib.lib().mmnn_densenet_ws_offset(next(iter(bb._plans.values()))["plan"], b"#pack_launches", 0, 0)
+    m.eval()
+    with torch.no_grad():
+        y0 = bb(x)
+        assert packs() == 1
+        bb(x)
+        assert packs() == 2                                   # default policy: every forward
+        bb.repack_policy = "versioned"
+        y1 = bb(x); n = packs()
+        y2 = bb(x)
+        assert packs() == n and torch.equal(y1, y0) and torch.equal(y2, y0)      # unchanged parameters: no repack, same result
+        bb.conv0.weight.mul_(1.5)                             # in-place op on a Parameter: seen through its version counter
+        y3 = bb(x)
+        assert packs() == n + 1 and not torch.equal(y3, y0)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["backbone.denseblock1.denselayer1.layers.conv2.weight"] *= 0.5
+        m.load_state_dict(sd)
+        y4 = bb(x)
+        assert packs() == n + 2 and not torch.equal(y4, y3)
+    m.train()
+    opt = FusedSGD(m, lr=0.1)
+    bb(x).sum().backward()
+    before = packs()
+    opt.step()                                                # raw-pointer update -> mark_params_changed()
+    with torch.no_grad():
+        y5 = bb(x)
+    assert packs() == before + 1
+    m.eval()
+    with torch.no_grad():
+        ref = bb(x); bb.repack_policy = "always"; again = bb(x)
+    assert torch.equal(ref, again)
