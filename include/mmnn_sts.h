@@ -75,8 +75,9 @@ int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, in
 int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
 int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches);
-/* plan options.  "single_stream" (0/1): run the whole backward on the caller's stream instead of overlapping the weight-gradient
- * kernels on two side streams -- same results, un-overlapped kernel durations for profiling.  "params_version" (any non-zero
+/* plan options.  "side_streams" (0, 1 or 2; default 0): run the weight-gradient kernels of the backward on that many side streams
+ * beside the data-gradient chain instead of on the caller's stream -- same results.  "single_stream" (0/1): force 0 side streams
+ * (un-overlapped kernel durations for profiling).  "params_version" (any non-zero
  * number the caller changes whenever it changed a parameter; 0 = unknown, the default): the forward re-packs the weights only
  * when the version, the parameter buffer or the workspace differs from the last packed one. */
 int mmnn_densenet_set_option(void* plan, const char* name, int64_t value);

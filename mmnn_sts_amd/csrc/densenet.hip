@@ -231,8 +231,9 @@ static BnFwd bnfwd(const Plan& p, StatPtr st, const float* params, float* run, l
 }
 
 // (re)build the device job tables when the buffers they point into change
-static void build_tables(Plan& p, const float* params, float* run, char* ws) {
-  if (p.tab_params == params && p.tab_run == run && p.tab_ws == ws) return;
+// returns true when the tables were (re)built and have to be uploaded
+static bool build_tables(Plan& p, const float* params, float* run, char* ws) {
+  if (p.tab_params == params && p.tab_run == run && p.tab_ws == ws) return false;
   char* hj = static_cast<char*>(p.host_jobs);
   RunStatJob* rj = reinterpret_cast<RunStatJob*>(hj);
   PackJob* pj = reinterpret_cast<PackJob*>(hj + (p.o_jobs_pack - p.o_jobs_run));
@@ -300,6 +301,7 @@ static void build_tables(Plan& p, const float* params, float* run, char* ws) {
   p.gj_begin[nb] = ig;
   p.n_run_jobs = ir; p.n_pack_jobs = ip; p.n_grad_jobs = ig;
   p.tab_params = params; p.tab_run = run; p.tab_ws = ws;
+  return true;
 }
 
 // ---- live kernel timing ---------------------------------------------------------------------------------------------
@@ -356,6 +358,7 @@ int plan_read_timer(Plan& p, int kind, int block, double* total_ms, long* count)
 int plan_set_option(Plan& p, const char* name, long value) {
   const std::string s(name ? name : "");
   if (s == "single_stream") { p.single_stream = value != 0; return 0; }
+  if (s == "side_streams") { p.side_streams = value < 0 ? 0 : (value > 2 ? 2 : (int)value); p.side_tried = false; return 0; }
   if (s == "trace_buffer") { p.trace_base = reinterpret_cast<unsigned long long*>(value); p.trace_seq = 0; return 0; }   // device pointer, 0 = off
   if (s == "trace_slots") { p.trace_slots = (int)value; return 0; }
   if (s == "params_version") { p.params_version = value; return 0; }
@@ -385,10 +388,16 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
   double t_prev = host_timing ? now() : 0.0;
   auto lap = [&](int k) { if (host_timing) { const double t = now(); ht[k] += t - t_prev; t_prev = t; } };
-  build_tables(p, params, run, ws);
+  // The job tables hold pointers and counts only: they change when a buffer moves, in practice once.  Uploading them on every
+  // forward cost 0.85 ms of HOST time per step (hipMemcpyAsync from the pinned staging buffer returns only when the copy has
+  // been handed to the idle stream), which kept the enqueueing thread from ever running ahead of the GPU.
+  if (p.tab_params != params || p.tab_run != run || p.tab_ws != ws) {
+    if (p.tab_ws != nullptr) MMNN_HIP(hipStreamSynchronize(stream));   // an earlier upload from the same staging buffer may still be in flight
+    build_tables(p, params, run, ws);
+    lap(0);
+    MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
+  }
   p.trace_seq = 0;
-  lap(0);
-  MMNN_HIP(hipMemcpyAsync(ws + p.o_jobs_run, p.host_jobs, p.host_jobs_bytes, hipMemcpyHostToDevice, stream));
   lap(1);
   if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
   MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
@@ -558,15 +567,22 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
   // kernels only consume its products, so they run beside it on `side`, ordered by events.  Matters for the late dense blocks
   // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
+  // Streams.  The weight-gradient kernels only consume products of the data-gradient chain, so they CAN run beside it on side
+  // streams (option "side_streams" / MMNN_SIDE_STREAMS = 1 or 2).  Default 0: since the small blocks' weight gradients go out as
+  // batched launches that fill the chip, overlapping buys nothing any more and costs event hand-offs plus contention with the
+  // chain (r02, 2x2x128^3: 10.7 ms with two side streams, 10.0 with one, 9.9 with none; same ranking at 64^3; one side stream is
+  // 2 % ahead at 96^3).  Block 1's kernels cannot share a CU anyway (two waves per SIMD each).
+  static const int env_side = [] { const char* e = getenv("MMNN_SIDE_STREAMS"); return e ? atoi(e) : -1; }();
   static const bool env_single = [] { const char* e = getenv("MMNN_SINGLE_STREAM"); return e && e[0] == '1'; }();
-  const bool single = env_single || p.single_stream;   // profiling aid: serialise the backward on one stream (un-overlapped durations)
-  if (!single && !p.side && !p.side_tried) {
+  const int want_side = (env_single || p.single_stream) ? 0 : (env_side >= 0 ? env_side : p.side_streams);
+  const bool single = want_side <= 0;
+  if (!single && (!p.side || (want_side >= 2 && !p.side2)) && !p.side_tried) {
     p.side_tried = true;
-    if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
-    if (p.side && hipStreamCreateWithFlags(&p.side2, hipStreamNonBlocking) != hipSuccess) p.side2 = nullptr;
+    if (!p.side && hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) p.side = nullptr;
+    if (want_side >= 2 && p.side && !p.side2 && hipStreamCreateWithFlags(&p.side2, hipStreamNonBlocking) != hipSuccess) p.side2 = nullptr;
   }
   hipStream_t side = (p.side && !single) ? p.side : stream;        // conv2 weight gradients (+ the big gradient finalise)
-  hipStream_t side2 = (p.side2 && !single) ? p.side2 : side;       // conv1 weight gradients
+  hipStream_t side2 = (p.side2 && !single && want_side >= 2) ? p.side2 : side;   // conv1 weight gradients
   const bool two = side != stream;
   p.sync_used = 0;
   auto next_event = [&]() -> hipEvent_t {

@@ -79,7 +79,8 @@ struct Plan {
   std::vector<int> timer_tag;                      // class of each pair
   size_t timer_used = 0;
   double timer_ms[16 * MAX_BLOCKS] = {0}; long timer_count[16 * MAX_BLOCKS] = {0};   // [class][block]
-  bool single_stream = false;                      // option "single_stream": backward on the caller's stream only
+  bool single_stream = false;                      // option "single_stream": backward on the caller's stream only (overrides side_streams)
+  int side_streams = 0;                            // option "side_streams": 0 (default), 1 or 2 streams for the weight-gradient kernels
   long params_version = 0, packed_version = 0; const float* packed_params = nullptr; const char* packed_ws = nullptr;   // option "params_version"
   long pack_launches = 0;
   unsigned long long* trace_base = nullptr; mutable int trace_seq = 0; int trace_slots = 0;   // developer aid: per-launch phase stamps

@@ -178,3 +178,31 @@ def test_backbone_repeated_calls_are_bit_identical(in_ch):
             if ref_g is None:
                 ref_g = gr
             assert torch.equal(gr, ref_g), f"backward deviates by {float((gr - ref_g).abs().max())}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side", [1, 2])
+def test_backbone_side_streams_are_equivalent(side):
+    """Plan option "side_streams": the weight-gradient kernels on 1 or 2 side streams (event hand-offs) give bit-identical gradients
+    to the default single-stream schedule."""
+    import ctypes
+    from mmnn_sts_amd import _lib
+    from tests._native import NativeBackbone
+    cfg = R.DenseNetCfg(in_channels=2)
+    n, s = 2, 64
+    nb = NativeBackbone(cfg, n, s, s, s, dropout=0.2)
+    flat, run = nb.flatten(synth_sd(R.densenet_schema(cfg), "densenet."))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(n, 2, s, s, s, device="cuda", generator=g)
+    cot = torch.randn(nb.out_shape, device="cuda", generator=g)
+    nb.forward(flat, run.clone(), x, True, seed=9)
+    ref = nb.backward(flat, x, cot, seed=9).clone()
+    _lib.check(_lib.lib().mmnn_densenet_set_option(nb.plan, b"side_streams", side), "set_option")
+    for _ in range(2):
+        nb.forward(flat, run.clone(), x, True, seed=9)
+        got = nb.backward(flat, x, cot, seed=9)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all() and torch.equal(got, ref), float((got - ref).abs().max())
+    _lib.check(_lib.lib().mmnn_densenet_set_option(nb.plan, b"side_streams", 0), "set_option")
+    nb.forward(flat, run.clone(), x, True, seed=9)
+    assert torch.equal(nb.backward(flat, x, cot, seed=9), ref)
