@@ -148,11 +148,24 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   p.o_sl_conv0 = cv.take((size_t)p.ns_conv0 * cfg.in_channels * cfg.init_features * 352 * F);
   p.o_sl_c1.assign(nb, {}); p.o_sl_c2.assign(nb, {}); p.ns_c1.assign(nb, {}); p.ns_c2.assign(nb, {});
   p.o_sl_tr.clear(); p.ns_tr.clear();
+  // Layers per weight-gradient launch (MMNN_WGRAD_GROUP="a,b,c" for >= 32768 / >= 4096 / fewer voxels per batch; 0 = the whole
+  // dense block, the default).  With the backward on one stream the weight gradients of a block can all wait for the end of its
+  // data-gradient chain: one launch per kernel variant, and the voxel splits -- hence the partial slabs `finalize` has to read
+  // back -- shrink by the number of layers that share the launch.
+  {
+    int g[3] = {0, 0, 0};
+    if (const char* e = getenv("MMNN_WGRAD_GROUP")) sscanf(e, "%d,%d,%d", &g[0], &g[1], &g[2]);
+    for (int b = 0; b < nb; ++b) {
+      const long nvox = (long)N * p.Vb[b];
+      const int want = g[nvox >= 32768 ? 0 : nvox >= 4096 ? 1 : 2];
+      p.wg_group[b] = (want < 1 || want > cfg.block_layers[b]) ? cfg.block_layers[b] : want;
+    }
+  }
   for (int b = 0; b < nb; ++b) {
     for (int l = 0; l < cfg.block_layers[b]; ++l) {
       const int ci = p.layers[b][l].cin;
-      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci);
-      const int s2 = wgrad_pick_splits(27, N, p.Db[b], p.Hb[b], p.Wb[b], cfg.growth, p.mid);
+      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, p.wg_group[b]);
+      const int s2 = wgrad_pick_splits(27, N, p.Db[b], p.Hb[b], p.Wb[b], cfg.growth, p.mid, p.wg_group[b]);
       p.ns_c1[b].push_back(s1); p.ns_c2[b].push_back(s2);
       p.o_sl_c1[b].push_back(cv.take((size_t)s1 * p.mid * ci * F));
       p.o_sl_c2[b].push_back(cv.take((size_t)s2 * 27 * cfg.growth * p.mid * F));
@@ -631,14 +644,6 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   const WgradArgs* dev_w1 = dev_w2 + p.n_layers;
   struct PendingW { WgradArgs w2, w1; int b, id; };
   std::vector<PendingW> pend;        // consecutive layers in DESCENDING layer id
-  static int grp_cfg[3] = {1, 4, 8};   // layers per group for >= 32768 / >= 4096 / fewer voxels per batch
-  static const bool grp_init = [] {
-    const char* e = getenv("MMNN_WGRAD_GROUP");   // experiment knob: "a,b,c"
-    if (e) sscanf(e, "%d,%d,%d", &grp_cfg[0], &grp_cfg[1], &grp_cfg[2]);
-    for (int& g : grp_cfg) g = g < 1 ? 1 : g;
-    return true;
-  }();
-  (void)grp_init;
   static const bool no_batch = [] { const char* e = getenv("MMNN_NO_WGRAD_BATCH"); return e && e[0] == '1'; }();   // debugging aid
   auto flush = [&]() -> int {
     if (pend.empty()) return 0;
@@ -714,8 +719,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     const double cnt = (double)N * p.Vb[b];
     const long xns = (long)p.ctot_b[b] * p.Vb[b];
     const long tns = (long)p.mid * p.Vb[b];
-    const long nvox = (long)N * p.Vb[b];
-    const int grp = grp_cfg[nvox >= 32768 ? 0 : nvox >= 4096 ? 1 : 2];
+    const int grp = p.wg_group[b];
     for (int l = c.block_layers[b] - 1; l >= 0; --l) {
       --layer_id;
       const LayerOff& lo = p.layers[b][l];

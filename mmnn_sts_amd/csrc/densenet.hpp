@@ -62,6 +62,7 @@ struct Plan {
   size_t o_kz_part, o_kz_cnt;                       // cross-block K-split scratch (fprop.hpp)
   size_t o_jobs_run, o_jobs_pack, o_jobs_grad;
   int n_layers = 0;
+  int wg_group[MAX_BLOCKS] = {0};                  // dense layers per weight-gradient launch, by block
   size_t o_wg_table = 0;                            // device tables of the weight-gradient arguments (batched launches)
   void* wg_pinned = nullptr; std::vector<char> wg_shadow; bool wg_uploaded = false;
   void* host_jobs = nullptr; size_t host_jobs_bytes = 0;

@@ -14,14 +14,15 @@ static void wg3_tile(int W, int& TD, int& TH, int& TW) {
 
 static int wg1_wc(int Cin) { return Cin >= 256 ? 8 : (Cin >= 128 ? 4 : 2); }
 
-int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
+int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int batch) {
+  if (batch < 1) batch = 1;      // layers that share one launch: the block budget below is that of the whole launch
   if (taps == 27) {
     int TD, TH, TW;
     wg3_tile(W, TD, TH, TW);
     const long ntiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
     const int cgroups = cdiv(Cin, 32);
     static const int cap = [] { const char* e = getenv("MMNN_WG3_SPLIT_CAP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
-    long s = (cap > 64 ? 1024 : 512) / cgroups;
+    long s = (cap > 64 ? 1024 : 512) / ((long)cgroups * batch);
     if (s > cap) s = cap;
     if (s > ntiles / 2) s = ntiles / 2;
     return s < 1 ? 1 : (int)s;
@@ -34,7 +35,7 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin) {
   // multiplies), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
   static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
   const long groups = (long)cdiv(Cin, 32 * wc) * cdiv(M, 128);
-  long s = target / groups;
+  long s = target / (groups * batch);
   const long slab_cap = ((long)64 << 20) / ((long)M * Cin * 4);
   if (s > slab_cap) s = slab_cap;
   if (s > nchunks / 2) s = nchunks / 2;

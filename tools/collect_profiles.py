@@ -14,7 +14,8 @@ def find(pattern):
 
 
 for name, pat in (("bench_line.json", "bench_line.json"), ("bench_line_under_rocprof.json", "bench_under_rocprof.json"),
-                  ("kernel_stats_three_stream.csv", "prof_ov/**/*kernel_stats.csv"), ("kernel_stats_single_stream.csv", "prof_ss/**/*kernel_stats.csv"),
+                  ("kernel_stats_two_side_streams.csv", "prof_ov/**/*kernel_stats.csv"), ("kernel_stats.csv", "prof_ss/**/*kernel_stats.csv"),
+                  ("bench_line_two_side_streams.json", "bench_two_side_streams.json"),
                   ("gpu_tests.log", "gpu_tests.log")):
     f = find(pat)
     if f:
@@ -27,7 +28,7 @@ for grp in ("fetch", "write", "sq1", "sq2"):
     if not f:
         continue
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), f], capture_output=True, text=True, env=dict(os.environ, TOP="36")).stdout
-    txt.write(f"# pass '{grp}': MMNN_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc <counters below> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline\n")
+    txt.write(f"# pass '{grp}': rocprofv3 --kernel-trace --pmc <counters below> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline\n")
     txt.write(f"# per-launch means (FETCH_SIZE / WRITE_SIZE in KB; SQ_* summed over the chip)\n{out}\n")
 open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(txt.getvalue())
 
@@ -55,7 +56,7 @@ kernels = {
     "conv2_wgrad.b1": ("wgrad3_kernel<1, 1, 2, 32>", 2 * sl + t1 + 64 * w2, "read G and X slices, read T1, write 64 partial slabs"),
 }
 res = {"correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE counts wide reads at half size, MI355X_MICROARCH.md HBM section)",
-       "command": "MMNN_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline (separate passes)",
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline (separate passes)",
        "kernels": {}}
 for cls, (kname, alg, what) in kernels.items():
     fe, wr = mean_counter("fetch", kname, "FETCH_SIZE"), mean_counter("write", kname, "WRITE_SIZE")

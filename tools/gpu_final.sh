@@ -10,10 +10,10 @@ tail -12 $O/gpu_tests.log
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 cat $O/bench_line.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof_ov -o ov --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof_ov.err
-MMNN_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/prof_ss -o ss --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_ss.json 2> $O/prof_ss.err
+rocprofv3 --kernel-trace --stats -d $O/prof_ss -o ss --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof_ss.err
+MMNN_SIDE_STREAMS=2 rocprofv3 --kernel-trace --stats -d $O/prof_ov -o ov --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_two_side_streams.json 2> $O/prof_ov.err
 run() { name=$1; shift
-  MMNN_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$name -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$name -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$name.log 2>&1 || echo "pass $name failed"
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
