@@ -164,7 +164,14 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   for (int b = 0; b < nb; ++b) {
     for (int l = 0; l < cfg.block_layers[b]; ++l) {
       const int ci = p.layers[b][l].cin;
-      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, p.wg_group[b]);
+      // conv1: a launch covers the layers of the group that use the same channel-group width
+      int same = 0;
+      {
+        const int g0 = (cfg.block_layers[b] - 1 - l) / p.wg_group[b];          // groups are formed from the LAST layer downwards
+        for (int k = 0; k < cfg.block_layers[b]; ++k)
+          if ((cfg.block_layers[b] - 1 - k) / p.wg_group[b] == g0 && wgrad1_channel_width(p.layers[b][k].cin) == wgrad1_channel_width(ci)) ++same;
+      }
+      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, same);
       const int s2 = wgrad_pick_splits(27, N, p.Db[b], p.Hb[b], p.Wb[b], cfg.growth, p.mid, p.wg_group[b]);
       p.ns_c1[b].push_back(s1); p.ns_c2[b].push_back(s2);
       p.o_sl_c1[b].push_back(cv.take((size_t)s1 * p.mid * ci * F));
@@ -750,6 +757,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       WgradArgs w2, w1;
       layer_wgrad_args(p, params, run, ws, b, l, layer_id, seed, w2, w1);
       w2.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;   // developer aid
+      w1.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
       g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);

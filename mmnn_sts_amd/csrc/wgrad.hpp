@@ -525,8 +525,16 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
       }
     };
     int cur_n = -1;
+#if defined(MMNN_PHASE_TRACE)
+    const bool tracing = a.trace != nullptr && tid == 0 && split < 16 && c0 == 0 && m0 == 0;
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = tracing ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int k) { if (tracing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr[k] += t - tprev; tprev = t; } };
+#else
+    auto lap = [&](int) {};
+#endif
     if (k_begin < k_end) load_chunk(k_begin);
     coefficients();
+    lap(0);
     for (int ch = k_begin; ch < k_end; ++ch) {
       const int n = ch / chunks_per_n;
       if (n != cur_n) {
@@ -538,11 +546,24 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
         __syncthreads();
       }
       store_chunk();
+      lap(1);
       __syncthreads();
+      lap(2);
       if (ch + 1 < k_end) load_chunk(ch + 1);
+      lap(3);
       mfma_chunk();
+      lap(4);
       __syncthreads();
+      lap(5);
     }
+#if defined(MMNN_PHASE_TRACE)
+    if (tracing) {
+      for (int k = 0; k < 6; ++k) a.trace[split * 16 + k] = tr[k];
+      a.trace[split * 16 + 6] = (unsigned long long)(k_end - k_begin);
+      a.trace[10] = (1ull << 48) | (9ull << 40) | ((unsigned long long)a.M << 16) | (unsigned long long)a.Cin;
+      a.trace[11] = ((unsigned long long)gridDim.x << 32) | ((unsigned long long)gridDim.y << 16) | gridDim.z;
+    }
+#endif
   } else {
   coefficients();
   int cur_n = -1;

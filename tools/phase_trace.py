@@ -17,6 +17,7 @@ x = torch.randn(n, 2, s, s, s, device="cuda")
 cot = torch.randn(nb.out_shape, device="cuda")
 L = _lib.lib()
 _lib.check(L.mmnn_densenet_set_option(nb.plan, b"single_stream", 1), "opt")
+os.environ.setdefault("MMNN_NO_WGRAD_BATCH", "1")        # per-layer weight-gradient launches carry the trace pointer
 for _ in range(3):
     nb.forward(flat, run, x, True, seed=1); nb.backward(flat, x, cot, seed=1)
 torch.cuda.synchronize()
@@ -42,7 +43,7 @@ for i in range(SLOTS):
         blk = np.array([[int(t[i, b, k]) for k in range(7)] for b in range(16) if int(t[i, b, 6]) > 0], dtype=np.float64)
         if len(blk):
             m = np.median(blk, axis=0)
-            print(f"{i:3d}  wgrad3 M {M} Cin {cin} grid {gx},{gy},{gz}: tiles/block {m[6]:.0f} | first load+coef {m[0]:.0f} | per tile: store {m[1] / m[6]:.0f}  "
+            print(f"{i:3d}  wgrad{3 if taps == 27 else 1} M {M} Cin {cin} grid {gx},{gy},{gz}: tiles/block {m[6]:.0f} | first load+coef {m[0]:.0f} | per tile: store {m[1] / m[6]:.0f}  "
                   f"barrier {m[2] / m[6]:.0f}  load issue {m[3] / m[6]:.0f}  mfma {m[4] / m[6]:.0f}  barrier {m[5] / m[6]:.0f}  = {(m[1:6].sum()) / m[6]:.0f} cycles")
         continue
     rows = []
