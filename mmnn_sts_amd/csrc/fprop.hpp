@@ -687,68 +687,80 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   }
 
   if (kg == 0 && !loader) {
+  // The mask epilogues read one (ex) or two (ex, out) tensors per element.  Their loads are issued BEFORE the stores: `out` may
+  // alias `ex` as far as the compiler knows, so a load placed after a store is never hoisted above it and every accumulator row
+  // would pay a full memory round trip of its own (phase trace r02: 34 us of a 126 us block in block 1's data gradient).  One
+  // tensor (MASK_STORE): the whole tile's loads go out together; two tensors (MASK_ACCUM): one 32-row slab at a time (register
+  // budget: the big tiles of block 1 must stay at two waves per SIMD).  Element offsets are 32-bit (host check: M * V < 2^31),
+  // so an address costs one register beside the uniform base pointer.
+  constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
+  constexpr bool ALL_ROWS = (EPI == EPI_MASK_STORE);
+  float xall[ALL_ROWS ? MT : 1][ALL_ROWS ? 16 : 1][NT];
+  if (ALL_ROWS) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ml = wm * MT * 32 + i * 32 + acc_row(q, half);
+        const bool mok = (m0 + ml) < a.M;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;   // unconditional loads (clamped)
+          xall[ALL_ROWS ? i : 0][ALL_ROWS ? q : 0][j] = exn[o];
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float s0[16], s1[16];
-    // The mask epilogues read one (ex) or two (ex, out) tensors per element.  All of a tile row's loads are issued BEFORE its first
-    // store: `out` may alias `ex` as far as the compiler knows, so a load placed after a store is never hoisted above it and every
-    // accumulator row would pay a full memory round trip of its own (phase trace r02: 34 us of a 126 us block in block 1's data gradient).
-    // Rows are processed in batches of RB (register budget: the big tiles of block 1 must stay at two waves per SIMD).  Element
-    // offsets are 32-bit (host check: M * V < 2^31), so an address costs one register beside the uniform base pointer.
-    constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
-    constexpr int RB = (MT * NT >= 4) ? 8 : 16;
+    float xe[(MASK && !ALL_ROWS) ? 16 : 1][NT], go[(EPI == EPI_MASK_ACCUM) ? 16 : 1][NT];
+    if (MASK && !ALL_ROWS) {
 #pragma unroll
-    for (int rb = 0; rb < 16; rb += RB) {
-      float xe[MASK ? RB : 1][NT], go[(EPI == EPI_MASK_ACCUM) ? RB : 1][NT];
-      if (MASK) {
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {
-          const int ml = wm * MT * 32 + i * 32 + acc_row(rb + q, half);
-          const bool mok = (m0 + ml) < a.M;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;   // unconditional loads (clamped)
-            xe[MASK ? q : 0][j] = exn[o];
-            if (EPI == EPI_MASK_ACCUM) go[(EPI == EPI_MASK_ACCUM) ? q : 0][j] = outn[o];
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < RB; ++q) {
-        const int r = rb + q;
-        const int ml = wm * MT * 32 + i * 32 + acc_row(r, half);
+      for (int q = 0; q < 16; ++q) {
+        const int ml = wm * MT * 32 + i * 32 + acc_row(q, half);
         const bool mok = (m0 + ml) < a.M;
-        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const bool ok = mok && vok[j];
-          const unsigned o = (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j];
-          float val = acc[i][j][r];
-          if (EPI == EPI_STORE) {
-            if (ok) outn[o] = val;
-          } else if (EPI == EPI_STORE_STATS) {
-            val *= ecoef[5 * M_B + ml];
-            if (ok) {
-              outn[o] = val;
-              t0 += val;
-              t1 += val * val;
-            }
-          } else {
-            if (ok) {
-              const float x = xe[MASK ? q : 0][j];
-              const float pre = fmaf(ecoef[ml], x, ecoef[M_B + ml]);
-              const float z = pre > 0.f ? val : 0.f;
-              const float xh = (x - ecoef[2 * M_B + ml]) * ecoef[3 * M_B + ml];
-              t0 += z;
-              t1 += z * xh;
-              if (EPI == EPI_MASK_STORE) outn[o] = z;
-              else outn[o] = go[(EPI == EPI_MASK_ACCUM) ? q : 0][j] + ecoef[4 * M_B + ml] * z;
-            }
+          const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;
+          xe[(MASK && !ALL_ROWS) ? q : 0][j] = exn[o];
+          if (EPI == EPI_MASK_ACCUM) go[(EPI == EPI_MASK_ACCUM) ? q : 0][j] = outn[o];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * MT * 32 + i * 32 + acc_row(r, half);
+      const bool mok = (m0 + ml) < a.M;
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool ok = mok && vok[j];
+        const unsigned o = (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j];
+        float val = acc[i][j][r];
+        if (EPI == EPI_STORE) {
+          if (ok) outn[o] = val;
+        } else if (EPI == EPI_STORE_STATS) {
+          val *= ecoef[5 * M_B + ml];
+          if (ok) {
+            outn[o] = val;
+            t0 += val;
+            t1 += val * val;
+          }
+        } else {
+          if (ok) {
+            const float x = ALL_ROWS ? xall[ALL_ROWS ? i : 0][ALL_ROWS ? r : 0][j] : xe[(MASK && !ALL_ROWS) ? r : 0][j];
+            const float pre = fmaf(ecoef[ml], x, ecoef[M_B + ml]);
+            const float z = pre > 0.f ? val : 0.f;
+            const float xh = (x - ecoef[2 * M_B + ml]) * ecoef[3 * M_B + ml];
+            t0 += z;
+            t1 += z * xh;
+            if (EPI == EPI_MASK_STORE) outn[o] = z;
+            else outn[o] = go[(EPI == EPI_MASK_ACCUM) ? r : 0][j] + ecoef[4 * M_B + ml] * z;
           }
         }
-        s0[r] = t0;
-        s1[r] = t1;
       }
+      s0[r] = t0;
+      s1[r] = t1;
     }
     if (want_sums) {
       const float r0 = half_reduce16(s0, lane);
