@@ -53,7 +53,7 @@ w2 = 27 * 32 * 128 * 4
 kernels = {
     "conv2_fwd.b1": ("fprop_kernel<27, 1, 1, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>", t1 + sl + w2, "read T1, write the 32 new channels, weights"),
     "conv2_dgrad.b1": ("fprop_kernel<27, 2, 2, 2, 2, 1, 2, 2, 2, 1, 4, 32, false>", 2 * sl + 2 * t1 + w2, "read G and X slices, read T1 (mask), write dZ2, weights"),
-    "conv2_wgrad.b1": ("wgrad3_kernel<1, 1, 2, 32>", 2 * sl + t1 + 64 * w2, "read G and X slices, read T1, write 64 partial slabs"),
+    "conv2_wgrad.b1": ("wgrad3_batched_kernel<1, 1, 2, 32>", 6 * (2 * sl + t1 + 21 * w2), "ONE launch for the 6 layers of block 1: per layer read G and X slices, read T1, write 21 partial slabs"),
 }
 res = {"correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE counts wide reads at half size, MI355X_MICROARCH.md HBM section)",
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline (separate passes)",
