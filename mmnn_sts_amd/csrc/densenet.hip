@@ -164,14 +164,17 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   for (int b = 0; b < nb; ++b) {
     for (int l = 0; l < cfg.block_layers[b]; ++l) {
       const int ci = p.layers[b][l].cin;
-      // conv1: a launch covers the layers of the group that use the same channel-group width
-      int same = 0;
+      // conv1: a launch covers the layers of the group that use the same channel-group width; `pairs` = its (layer, channel
+      // group) pairs, so that every block of the launch walks the same number of voxel chunks
+      int pairs = 0;
       {
         const int g0 = (cfg.block_layers[b] - 1 - l) / p.wg_group[b];          // groups are formed from the LAST layer downwards
+        const int cw = wgrad1_channel_width(ci);
         for (int k = 0; k < cfg.block_layers[b]; ++k)
-          if ((cfg.block_layers[b] - 1 - k) / p.wg_group[b] == g0 && wgrad1_channel_width(p.layers[b][k].cin) == wgrad1_channel_width(ci)) ++same;
+          if ((cfg.block_layers[b] - 1 - k) / p.wg_group[b] == g0 && wgrad1_channel_width(p.layers[b][k].cin) == cw)
+            pairs += cdiv(p.layers[b][k].cin, cw);
       }
-      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, same);
+      const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, pairs);
       const int s2 = wgrad_pick_splits(27, N, p.Db[b], p.Hb[b], p.Wb[b], cfg.growth, p.mid, p.wg_group[b]);
       p.ns_c1[b].push_back(s1); p.ns_c2[b].push_back(s2);
       p.o_sl_c1[b].push_back(cv.take((size_t)s1 * p.mid * ci * F));

@@ -12,7 +12,9 @@ static void wg3_tile(int W, int& TD, int& TH, int& TW) {
   else { TD = 4; TH = 4; TW = 4; }
 }
 
-static int wg1_wc(int Cin) { return Cin >= 256 ? 8 : (Cin >= 128 ? 4 : 2); }
+// channel-group width: 8 waves x 32 channels from 256 input channels on, else 4 waves (2-wave blocks spent more time staging the
+// 128-row dOut operand than multiplying; with 4 waves the ones beyond Cin just help staging)
+static int wg1_wc(int Cin) { return Cin >= 256 ? 8 : 4; }
 
 int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int batch) {
   if (batch < 1) batch = 1;      // layers that share one launch: the block budget below is that of the whole launch
@@ -30,12 +32,15 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
   const long V = (long)D * H * W;
   const long nchunks = (long)N * cdiv(V, 64);
   const int wc = wg1_wc(Cin);
-  // Each block owns a (128 x 32*wc) tile of the weight gradient and loops over its share of the 64-voxel chunks; a chunk
-  // costs ~3.4 us of MFMA per CU, so the splits are chosen to give every CU about two blocks (one staging while the other
-  // multiplies), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
-  static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  // Each block owns a (128 x 32*wc) tile of the weight gradient and loops over its share of the 64-voxel chunks.  The kernel is
+  // HBM-heavy at block 1 (every (layer, channel group) pair re-reads the 128-row dOut operand: ~0.9 GB per launch), so what
+  // matters is balance: ~1536 equal blocks per launch = three rounds of two blocks per CU measured best (r02: 346 / 312 / 279 /
+  // 273 / 296 us at 512 / 768 / 1536 / 2048 / 3072), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
+  static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
   const long groups = (long)cdiv(Cin, 32 * wc) * cdiv(M, 128);
-  long s = target / (groups * batch);
+  // batch > 1: the number of (layer, channel group) pairs that share the launch -- every block of the launch then gets the same
+  // number of chunks, whatever its layer's channel count
+  long s = batch > 1 ? target / batch : target / groups;
   const long slab_cap = ((long)64 << 20) / ((long)M * Cin * 4);
   if (s > slab_cap) s = slab_cap;
   if (s > nchunks / 2) s = nchunks / 2;

@@ -439,6 +439,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const float* al = As + l31 * S + 32 * half;
   const float* bl = Bs + (wave * 32 + l31) * S + 32 * half;
+  const bool wave_has_channels = c0 + wave * 32 < a.Cin;
   const bool vec = (V & 3) == 0 && ((((uintptr_t)a.x | (uintptr_t)a.g0 | (uintptr_t)a.g1) & 15) == 0);
 
   // ---- MFMA over one staged chunk of 64 voxels: 32 k-steps x 4 output-channel tiles, operand reads one step ahead ----
@@ -551,7 +552,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
       lap(2);
       if (ch + 1 < k_end) load_chunk(ch + 1);
       lap(3);
-      mfma_chunk();
+      if (wave_has_channels) mfma_chunk();   // waves whose 32 channels lie beyond Cin only help staging (Cin = 64 / 96 with WC = 4)
       lap(4);
       __syncthreads();
       lap(5);
@@ -625,7 +626,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
       }
     }
     __syncthreads();
-    mfma_chunk();
+    if (wave_has_channels) mfma_chunk();
     __syncthreads();
   }
   }
