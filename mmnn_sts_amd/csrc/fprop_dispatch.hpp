@@ -56,6 +56,7 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
   if constexpr (TAPS == 1) {   // constexpr: a 1x1 instantiation must not drag the nine 3x3x3 kernels into its translation unit
     const long blocks_a = (long)a.N * cdiv(V, 128) * cdiv(a.M, 128);
     const long blocks_b = (long)a.N * cdiv(V, 64) * cdiv(a.M, 64);
+    // (r02: forcing the 64-wide tile at 32^3 is far slower -- conv1 forward 39 -> 56 us, data gradient 63 -> 109 us.)
     // 128-wide tile: KC = 8 / 16 / 32 measure the same (37 us at 32^3: a fixed ~17 us of prologue, output write and statistics,
     // then 0.15 us per input channel = 115 TFLOP/s).  64-wide tile: deep chunks, 4x fewer barriers than KC = 16 (25 -> 17 us at 16^3).
     if (blocks_a >= 192) return launch_cfg<1, PRO, EPI, 2, 2, 1, 2, 2, 16, 1, 1, 128>(a, s);
