@@ -274,6 +274,29 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     int xv_off[XV_IT], xv_dst[XV_IT], xv_cl[XV_IT];
     int xh_off[XH_IT > 0 ? XH_IT : 1], xh_dst[XH_IT > 0 ? XH_IT : 1], xh_cl[XH_IT > 0 ? XH_IT : 1];
     int w_off[W_IT], w_cl[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int it = ltid + i * NL;
+      const int q = it % (M_B / 4), kr = it / (M_B / 4);
+      const bool ok = (it < W_ITEMS) && (m0 + 4 * q < a.M);
+      w_off[i] = ok ? kr * a.w_ld + m0 + 4 * q : -1;
+      w_cl[i] = kr / TAPS;
+    }
+    auto load_w = [&](int c0, Stage& st) {
+      const int crem = a.Cin - c0;
+      const float* bw = a.w + (long)c0 * TAPS * a.w_ld;
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const bool ok = w_off[i] >= 0 && w_cl[i] < crem;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? bw + w_off[i] : a.w);
+        st.wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    // Small tiles: the first chunk's weight loads go out NOW, before the activation descriptors are worked out -- that set-up
+    // arithmetic is ~2 us of the small-extent kernels and now overlaps the (always cold) weight fetch.
+    constexpr bool EARLY = (MT * NT == 1) || (TAPS == 27 && TW <= 16);
+    const bool first_chunk_mine = (c_begin < c_end) && (!SPEC || loader);
+    if (EARLY && first_chunk_mine) load_w(c_begin, stA);
     {
       // 32-bit offsets: this path is only taken when KC * V < 2^30 (64-bit multiplies cost four instructions each, and this
       // set-up runs before the first load of every launch: 2.5 us of the 8^3 / 4^3 kernels in the phase trace)
@@ -314,20 +337,12 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         xh_dst[i] = lrow + ((it & 1) ? TW + 4 : 3);
         xh_cl[i] = cl;
       }
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i) {
-        const int it = ltid + i * NL;
-        const int q = it % (M_B / 4), kr = it / (M_B / 4);
-        const bool ok = (it < W_ITEMS) && (m0 + 4 * q < a.M);
-        w_off[i] = ok ? kr * a.w_ld + m0 + 4 * q : -1;
-        w_cl[i] = kr / TAPS;
-      }
     }
 
     // NOTE: every load below is UNCONDITIONAL (out-of-range items read element 0 of their tensor and are zeroed when
     // they are written to LDS).  A load under a divergent `if` makes hipcc branch around it and wait vmcnt(0) at the join,
     // which serialises the whole batch (one memory round trip per item instead of one per chunk).
-    auto load_chunk = [&](int c0, Stage& st) {
+    auto load_x = [&](int c0, Stage& st) {
       unsigned okv = 0, okh = 0;
       const float* b0 = in0n + (long)c0 * V;
       const float* b1 = GR ? in1n + (long)c0 * V : nullptr;
@@ -348,15 +363,11 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         st.xh0[i] = ok ? b0[off] : in0n[0];
         if (GR) st.xh1[i] = ok ? b1[off] : in1n[0];
       }
-      const float* bw = a.w + (long)c0 * TAPS * a.w_ld;
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i) {
-        const bool ok = w_off[i] >= 0 && w_cl[i] < crem;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? bw + w_off[i] : a.w);
-        st.wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
       st.okv = okv; st.okh = okh;
     };
+
+    auto load_chunk = [&](int c0, Stage& st) { load_x(c0, st); load_w(c0, st); };
+    auto load_first = [&](Stage& st) { if (EARLY) load_x(c_begin, st); else load_chunk(c_begin, st); };   // EARLY: weights already in flight
 
     auto store_chunk = [&](int c0, const Stage& st, int boff = 0) {
       const unsigned okv = st.okv, okh = st.okh;
@@ -387,7 +398,6 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     // Small tiles (the 16^3 .. 4^3 layers) are latency chains: issue the first chunk's loads, THEN compute the coefficients.  The
     // big tiles of block 1 amortise the prologue over a long K loop and cannot afford the registers (staging registers live
     // across the fp64 coefficient math: 116 -> 188 VGPRs, one register short of losing the second wave per SIMD).
-    constexpr bool EARLY = (MT * NT == 1) || (TAPS == 27 && TW <= 16);
     if (!EARLY) prologue();
     auto prefetch_next_weights = [&]() {
       if (a.pf_ptr == nullptr) return;
@@ -398,7 +408,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     };
     if (SPEC) {
       // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
-      if (loader && c_begin < c_end) load_chunk(c_begin, stA);
+      if (loader && c_begin < c_end) load_first(stA);
       prefetch_next_weights();
       stamp(1);
       if (EARLY) prologue();
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         __syncthreads();
       }
     } else if (PF == 1) {
-      if (c_begin < c_end) load_chunk(c_begin, stA);
+      if (c_begin < c_end) load_first(stA);
       prefetch_next_weights();
       stamp(1);
       if (EARLY) prologue();
@@ -430,7 +440,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         __syncthreads();
       }
     } else {
-      if (c_begin < c_end) load_chunk(c_begin, stA);
+      if (c_begin < c_end) load_first(stA);
       if (c_begin + KC < c_end) load_chunk(c_begin + KC, stB);
       prefetch_next_weights();
       stamp(1);
