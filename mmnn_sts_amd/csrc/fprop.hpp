@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     // Giving XCD x the x-th CONTIGUOUS eighth of the tile sequence makes neighbouring tiles -- which share halo rows and, for
     // the 1x1x1 kernels, nothing -- meet in the same L2 instead of each pulling the halo from HBM / the Infinity Cache again.
     int b = blockIdx.x;
+    // (Applying the same order to the 1x1x1 kernels, so that producer and consumer tiles share an XCD, measured no gain: r02.)
     if (TAPS == 27 && (gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
     if (TAPS == 27) {
       const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;

@@ -14,7 +14,7 @@ static void wg3_tile(int W, int& TD, int& TH, int& TW) {
 
 // channel-group width: 8 waves x 32 channels from 256 input channels on, else 4 waves (2-wave blocks spent more time staging the
 // 128-row dOut operand than multiplying; with 4 waves the ones beyond Cin just help staging)
-static int wg1_wc(int Cin) { return Cin >= 256 ? 8 : 4; }
+static int wg1_wc(int Cin) { static const int thr = [] { const char* e = getenv("MMNN_WG1_WC8_FROM"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }(); return Cin >= thr ? 8 : 4; }
 
 int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int batch) {
   if (batch < 1) batch = 1;      // layers that share one launch: the block budget below is that of the whole launch

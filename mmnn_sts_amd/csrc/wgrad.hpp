@@ -45,6 +45,9 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
 #if defined(__HIPCC__)
 
 // ----------------------------------------------------------------------------------------------------------------
+// (r02: a loader / compute wave specialisation of this kernel -- waves 0-3 stage tile t+1 into a second LDS buffer and take one tap,
+// waves 4-7 take 6,6,6,5 taps, one barrier per tile -- measured 10 % SLOWER at 32^3 (1000 vs 905 us for block 1's six layers), 13 %
+// with s_setprio 1 on the compute waves: moving work between the two waves of a SIMD did not net, as MI355X_MICROARCH.md warns.)
 // 3x3x3:  block = 8 waves sharing the 27 taps 3,3,3,3,3,4,4,4 (two waves per SIMD: 6/7/7/7 tap-units per SIMD, 96 % balanced;
 // 9 waves of 3 taps would put 3 waves on one SIMD and 2 on the others), one 32-channel group of c, <= 4 accumulator tiles per wave.
 // ----------------------------------------------------------------------------------------------------------------
