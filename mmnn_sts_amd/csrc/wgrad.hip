@@ -47,75 +47,13 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
   return s < 1 ? 1 : (int)s;
 }
 
-template <int PRO_X, int TD, int TH, int TW>
-static int launch3(const WgradArgs& a, hipStream_t stream) {
-  using C = Wg3Cfg<TD, TH, TW>;
-  auto kern = wgrad3_kernel<PRO_X, TD, TH, TW>;
-  const size_t smem = C::smem_bytes();
-  static bool configured[MAX_DEVICES] = {false};   // per device
-  bool& conf = configured[current_device_slot()];
-  if (!conf) {
-    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    conf = true;
-  }
-  MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32)), dim3(C::NTHREADS), smem, stream, a);
-  MMNN_HIP(hipGetLastError());
-  return 0;
-}
-
-template <int PRO_X, int WC>
-static int launch1(const WgradArgs& a, hipStream_t stream) {
-  using C = Wg1Cfg<WC>;
-  auto kern = wgrad1_kernel<PRO_X, WC>;
-  const size_t smem = C::smem_bytes();
-  static bool configured[MAX_DEVICES] = {false};   // per device
-  bool& conf = configured[current_device_slot()];
-  if (!conf) {
-    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    conf = true;
-  }
-  MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
-  MMNN_HIP(hipGetLastError());
-  return 0;
-}
-
 int wgrad1_channel_width(int Cin) { return 32 * wg1_wc(Cin); }
 
-template <int PRO_X, int TD, int TH, int TW>
-static int launch3_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream) {
-  using C = Wg3Cfg<TD, TH, TW>;
-  auto kern = wgrad3_batched_kernel<PRO_X, TD, TH, TW>;
-  const size_t smem = C::smem_bytes();
-  static bool configured[MAX_DEVICES] = {false};   // per device
-  bool& conf = configured[current_device_slot()];
-  if (!conf) {
-    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    conf = true;
-  }
-  int gx = 1, gy = 1;
-  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32)); }
-  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
-  MMNN_HIP(hipGetLastError());
-  return 0;
-}
-
-template <int PRO_X, int WC>
-static int launch1_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream) {
-  using C = Wg1Cfg<WC>;
-  auto kern = wgrad1_batched_kernel<PRO_X, WC>;
-  const size_t smem = C::smem_bytes();
-  static bool configured[MAX_DEVICES] = {false};   // per device
-  bool& conf = configured[current_device_slot()];
-  if (!conf) {
-    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    conf = true;
-  }
-  int gx = 1, gy = 1;
-  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32 * WC)); }
-  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
-  MMNN_HIP(hipGetLastError());
-  return 0;
-}
+// kernel translation units
+int wgrad3_launch(const WgradArgs& a, int pro_x, hipStream_t s);
+int wgrad3_launch_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream);
+int wgrad1_launch(const WgradArgs& a, int pro_x, int wc, hipStream_t s);
+int wgrad1_launch_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, int wc, hipStream_t stream);
 
 int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, int taps, int pro_x, hipStream_t stream) {
   MMNN_REQUIRE(host && dev && count >= 1 && count <= 65535, "wgrad batch: bad table (count %d)", count);
@@ -133,30 +71,8 @@ int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev, int count,
     MMNN_REQUIRE(taps == 27 ? a.M <= 32 : a.M <= 128, "wgrad batch: %d output channels exceed one block row", a.M);
     MMNN_REQUIRE(taps == 27 || wg1_wc(a.Cin) == wg1_wc(f.Cin), "wgrad batch: layer %d needs another channel-group width", i);
   }
-  if (taps == 27) {
-    if (f.W > 16) return launch3_batched<PRO_BNRELU, 1, 2, 32>(host, dev, count, seed, stream);
-    if (f.W > 8) return launch3_batched<PRO_BNRELU, 1, 4, 16>(host, dev, count, seed, stream);
-    if (f.W > 4) return launch3_batched<PRO_BNRELU, 2, 4, 8>(host, dev, count, seed, stream);
-    return launch3_batched<PRO_BNRELU, 4, 4, 4>(host, dev, count, seed, stream);
-  }
-  const int wc = wg1_wc(f.Cin);
-  if (wc == 8) return launch1_batched<PRO_BNRELU, 8>(host, dev, count, seed, stream);
-  if (wc == 4) return launch1_batched<PRO_BNRELU, 4>(host, dev, count, seed, stream);
-  return launch1_batched<PRO_BNRELU, 2>(host, dev, count, seed, stream);
-}
-
-template <int PRO_X>
-static int dispatch(const WgradArgs& a, int taps, hipStream_t s) {
-  if (taps == 27) {
-    if (a.W > 16) return launch3<PRO_X, 1, 2, 32>(a, s);
-    if (a.W > 8) return launch3<PRO_X, 1, 4, 16>(a, s);
-    if (a.W > 4) return launch3<PRO_X, 2, 4, 8>(a, s);
-    return launch3<PRO_X, 4, 4, 4>(a, s);
-  }
-  const int wc = wg1_wc(a.Cin);
-  if (wc == 8) return launch1<PRO_X, 8>(a, s);
-  if (wc == 4) return launch1<PRO_X, 4>(a, s);
-  return launch1<PRO_X, 2>(a, s);
+  if (taps == 27) return wgrad3_launch_batched(host, dev, count, seed, stream);
+  return wgrad1_launch_batched(host, dev, count, seed, wg1_wc(f.Cin), stream);
 }
 
 int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream) {
@@ -168,10 +84,8 @@ int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream) {
   MMNN_REQUIRE(taps == 1 || taps == 27, "wgrad: taps must be 1 or 27");
   MMNN_REQUIRE(taps != 27 || a.M <= 32, "wgrad: the 3x3x3 kernel handles at most 32 output channels (growth rate), got %d", a.M);
   MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");
-  if (pro_x == PRO_BNRELU) return dispatch<PRO_BNRELU>(a, taps, stream);
-  if (pro_x == PRO_NONE) return dispatch<PRO_NONE>(a, taps, stream);
-  set_error("wgrad: unsupported input prologue %d", pro_x);
-  return 1;
+  MMNN_REQUIRE(pro_x == PRO_BNRELU || pro_x == PRO_NONE, "wgrad: unsupported input prologue %d", pro_x);
+  return taps == 27 ? wgrad3_launch(a, pro_x, stream) : wgrad1_launch(a, pro_x, wg1_wc(a.Cin), stream);
 }
 
 }  // namespace mmnn

@@ -1,0 +1,51 @@
+// 1x1x1 weight-gradient kernels: instantiations + launches (see wgrad_k3.hip).
+#include <algorithm>
+
+#include "wgrad.hpp"
+
+namespace mmnn {
+
+template <int PRO_X, int WC>
+static int launch1(const WgradArgs& a, hipStream_t stream) {
+  using C = Wg1Cfg<WC>;
+  auto kern = wgrad1_kernel<PRO_X, WC>;
+  const size_t smem = C::smem_bytes();
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    conf = true;
+  }
+  MMNN_LAUNCH(kern, dim3(a.nsplit, cdiv(a.Cin, 32 * WC), cdiv(a.M, 128)), dim3(C::NTHREADS), smem, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int PRO_X, int WC>
+static int launch1_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, hipStream_t stream) {
+  using C = Wg1Cfg<WC>;
+  auto kern = wgrad1_batched_kernel<PRO_X, WC>;
+  const size_t smem = C::smem_bytes();
+  static bool configured[MAX_DEVICES] = {false};   // per device
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    conf = true;
+  }
+  int gx = 1, gy = 1;
+  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32 * WC)); }
+  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int wgrad1_launch(const WgradArgs& a, int pro_x, int wc, hipStream_t s) {
+  if (pro_x == PRO_BNRELU) return wc == 8 ? launch1<PRO_BNRELU, 8>(a, s) : launch1<PRO_BNRELU, 4>(a, s);
+  return wc == 8 ? launch1<PRO_NONE, 8>(a, s) : launch1<PRO_NONE, 4>(a, s);
+}
+
+int wgrad1_launch_batched(const WgradArgs* host, const WgradArgs* dev, int count, uint64_t seed, int wc, hipStream_t stream) {
+  return wc == 8 ? launch1_batched<PRO_BNRELU, 8>(host, dev, count, seed, stream) : launch1_batched<PRO_BNRELU, 4>(host, dev, count, seed, stream);
+}
+
+}  // namespace mmnn
