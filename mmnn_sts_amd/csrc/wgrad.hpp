@@ -60,13 +60,17 @@ struct Wg3Cfg {
   static constexpr int NTHREADS = 8 * 64;
   static_assert(VT == 64, "tile must hold 64 voxels (two per MFMA k-step, 32 steps)");
   static_assert(32 % TW == 0, "tile width must divide 32");
-  static size_t smem_bytes() { return sizeof(float) * (32 * XS + 32 * YS + 3 * 32 + 2 * 32 + 3 * 32); }
+  static constexpr int STAGE = 32 * XS + 32 * YS;   // floats of one staged tile: input halo box + dOut
+  static size_t smem_bytes() { return sizeof(float) * (2 * STAGE + 3 * 32 + 2 * 32 + 3 * 32); }   // two tiles: see wgrad3_body
 };
 
 // MFMA over one staged 64-voxel tile for NTP taps: 32 k-steps; the operand reads of step s+1 are issued before the MFMAs of
 // step s (two register sets).  Accumulators are passed by reference so that they stay in registers in both instantiations.
-template <int NTP, int TD, int TH, int TW>
-__device__ __forceinline__ void wg3_mfma(f32x16 (&acc)[4], const float* yl, const float* x0, const float* x1, const float* x2, const float* x3) {
+// filler(s) is called once per k-step, between the MFMA groups: the caller's staging work for the NEXT tile (BN+ReLU, LDS writes into
+// the other buffer, global loads of the tile after) issues in the shadow of this wave's own MFMAs -- the matrix pipe is busy 64 cycles
+// per instruction, an in-order wave has nothing else to issue meanwhile.
+template <int NTP, int TD, int TH, int TW, class F>
+__device__ __forceinline__ void wg3_mfma(f32x16 (&acc)[4], const float* yl, const float* x0, const float* x1, const float* x2, const float* x3, F&& filler) {
   constexpr int RS = Wg3Cfg<TD, TH, TW>::RS, HS = Wg3Cfg<TD, TH, TW>::HS;
   float a0, a1, b0[4], b1[4];
   auto rd = [&](int s, float& av, float (&bv)[4]) {
@@ -89,10 +93,12 @@ __device__ __forceinline__ void wg3_mfma(f32x16 (&acc)[4], const float* yl, cons
     __builtin_amdgcn_sched_group_barrier(0x100, NTP + 1, 0);
     mm(a0, b0);
     __builtin_amdgcn_sched_group_barrier(0x008, NTP, 0);
+    filler(s);
     if (s + 2 < 32) rd(s + 2, a0, b0);
     __builtin_amdgcn_sched_group_barrier(0x100, NTP + 1, 0);
     mm(a1, b1);
     __builtin_amdgcn_sched_group_barrier(0x008, NTP, 0);
+    filler(s + 1);
   }
 }
 
@@ -101,9 +107,9 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
   using C = Wg3Cfg<TD, TH, TW>;
   constexpr int RS = C::RS, HS = C::HS, DS = C::DS, XS = C::XS, YS = C::YS, NTHREADS = C::NTHREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                 // [32 c][XS]
+  float* Xs = smem;                 // [32 c][XS]   (tile buffer 0; buffer 1 follows at + C::STAGE)
   float* Ys = Xs + 32 * XS;         // [32 m][YS]
-  float* gcoef = Ys + 32 * YS;      // p,q,r for the 32 rows of dOut
+  float* gcoef = smem + 2 * C::STAGE;   // p,q,r for the 32 rows of dOut
   float* xcoef = gcoef + 96;        // a,b for the 32 input channels
   float* gbase = xcoef + 64;        // p,q,r before the per-sample dropout scale
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -148,10 +154,11 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
 
   // ---- MFMA over one staged tile: 32 k-steps (2 voxels each) x 3 taps; operand reads of step s+1 issued before the
   // MFMAs of step s (two register sets) ----
-  auto mfma_tile = [&]() {   // wave-uniform choice of the tap count
-    if (ntap == 4) wg3_mfma<4, TD, TH, TW>(acc, yl, xb[0], xb[1], xb[2], xb[3]);
-    else wg3_mfma<3, TD, TH, TW>(acc, yl, xb[0], xb[1], xb[2], xb[2]);
+  auto mfma_tile = [&](int boff, auto&& filler) {   // wave-uniform choice of the tap count; boff: float offset of the tile buffer
+    if (ntap == 4) wg3_mfma<4, TD, TH, TW>(acc, yl + boff, xb[0] + boff, xb[1] + boff, xb[2] + boff, xb[3] + boff, filler);
+    else wg3_mfma<3, TD, TH, TW>(acc, yl + boff, xb[0] + boff, xb[1] + boff, xb[2] + boff, xb[2] + boff, filler);
   };
+  auto no_filler = [](int) {};
   auto tile_origin = [&](int tile, int& n, int& d0, int& h0, int& w0) {
     int b = tile;
     w0 = (b % nw) * TW; b /= nw;
@@ -239,40 +246,63 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
         y1[i] = *reinterpret_cast<const f32x4*>(g1n + g);
       }
     };
-    auto store_tile = [&](int) {
+    // Tile-invariant coefficients of this thread's items, in registers: the per-tile stores then read nothing from LDS.
+    float xv_a[XV_IT], xv_b[XV_IT], xh_a[XH_IT], xh_b[XH_IT];
+    float yb_p[Y_IT], yb_q[Y_IT], yb_r[Y_IT], y_p[Y_IT], y_q[Y_IT], y_r[Y_IT];
+    int ld_n = -1, st_n = -1;     // sample of the tile held in the staging registers / sample the dOut coefficients are scaled for
+    auto item_coefficients = [&]() {
+#pragma unroll
+      for (int i = 0; i < XV_IT; ++i) { const int cl = xv_k[i] & 31; xv_a[i] = xcoef[cl]; xv_b[i] = xcoef[32 + cl]; }
+#pragma unroll
+      for (int i = 0; i < XH_IT; ++i) { const int cl = xh_k[i] & 31; xh_a[i] = xcoef[cl]; xh_b[i] = xcoef[32 + cl]; }
+#pragma unroll
+      for (int i = 0; i < Y_IT; ++i) { const int m = y_k[i] & 31; yb_p[i] = gbase[m]; yb_q[i] = gbase[32 + m]; yb_r[i] = gbase[64 + m]; }
+    };
+    // The staging work of one tile in NUNITS pieces (one item each), so that the MFMA loop can take one piece per k-step.
+    constexpr int NUNITS = XV_IT + XH_IT + Y_IT + 1;
+    auto store_unit = [&](int u, float* X, float* Y) {
+      if (u == 0) {
+        if (ld_n != st_n) {   // dropout scale depends on the sample (wave-uniform, at most once per block and sample)
+#pragma unroll
+          for (int i = 0; i < Y_IT; ++i) {
+            const float sc = drop_scale(a.drop, ld_n, y_k[i] & 31);
+            y_p[i] = yb_p[i] * sc; y_q[i] = yb_q[i] * sc; y_r[i] = yb_r[i] * sc;
+          }
+          st_n = ld_n;
+        }
+        return;
+      }
+      u -= 1;
 #pragma unroll
       for (int i = 0; i < XV_IT; ++i) {
-        if (tid + i * NTHREADS < XV_ITEMS) {
-          const int cl = xv_k[i] & 255;
+        if (i == u && tid + i * NTHREADS < XV_ITEMS) {
           const bool ok = (okv >> i) & 1u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xv[i][e], xcoef[32 + cl]), 0.f) : xv[i][e];
-            Xs[xv_l[i] + e] = ok ? o : 0.f;
+            const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xv_a[i], xv[i][e], xv_b[i]), 0.f) : xv[i][e];
+            X[xv_l[i] + e] = ok ? o : 0.f;
           }
         }
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
-        if (tid + i * NTHREADS < XH_ITEMS) {
-          const int cl = xh_k[i] & 255;
-          const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xcoef[cl], xh[i], xcoef[32 + cl]), 0.f) : xh[i];
-          Xs[xh_l[i]] = ((okh >> i) & 1u) ? o : 0.f;
+        if (XV_IT + i == u && tid + i * NTHREADS < XH_ITEMS) {
+          const float o = (PRO_X == PRO_BNRELU) ? fmaxf(fmaf(xh_a[i], xh[i], xh_b[i]), 0.f) : xh[i];
+          X[xh_l[i]] = ((okh >> i) & 1u) ? o : 0.f;
         }
       }
 #pragma unroll
       for (int i = 0; i < Y_IT; ++i) {
         const int it = tid + i * NTHREADS;
-        if (it < Y_ITEMS) {
+        if (XV_IT + XH_IT + i == u && it < Y_ITEMS) {
           const int m = it >> 4, t = 4 * (it & 15);
           const bool ok = (oky >> i) & 1u;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            Ys[m * YS + t + e] = ok ? fmaf(gcoef[m], y0[i][e], fmaf(gcoef[32 + m], y1[i][e], gcoef[64 + m])) : 0.f;
+            Y[m * YS + t + e] = ok ? fmaf(y_p[i], y0[i][e], fmaf(y_q[i], y1[i][e], y_r[i])) : 0.f;
         }
       }
     };
-    int cur_n = -1;
 #if defined(MMNN_PHASE_TRACE)
     const bool tracing = a.trace != nullptr && tid == 0 && split < 16 && cg == 0;
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = tracing ? __builtin_amdgcn_s_memtime() : 0;
@@ -280,27 +310,46 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
 #else
     auto lap = [&](int) {};
 #endif
-    if (t_begin < t_end) load_tile(t_begin);
-    coefficients();
-    lap(0);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // Software pipeline over the block's tiles, two LDS buffers: while the MFMAs of tile t run out of buffer t&1, the same waves
+    // write tile t+1 (already in registers) into the other buffer and then issue the global loads of tile t+2 -- all of it between
+    // their own MFMAs.  One barrier per tile.  (r02 phase trace of the former store / barrier / MFMA / barrier sequence: 5.6k of a
+    // tile's 19.9k cycles had the matrix pipe idle, both waves of each SIMD staging in lockstep.)
+    if (t_begin < t_end) {
       int n, d0, h0, w0;
-      tile_origin(tile, n, d0, h0, w0);
-      if (n != cur_n) {   // dropout scale depends on the sample: refresh the dOut coefficients (previous tile fully consumed)
-        if (tid < 32) {
-          const float sc = drop_scale(a.drop, n, tid);
-          gcoef[tid] = gbase[tid] * sc; gcoef[32 + tid] = gbase[32 + tid] * sc; gcoef[64 + tid] = gbase[64 + tid] * sc;
-        }
-        cur_n = n;
-        __syncthreads();
+      tile_origin(t_begin, n, d0, h0, w0);
+      load_tile(t_begin); ld_n = n;
+    }
+    coefficients();
+    __syncthreads();
+    item_coefficients();
+    if (t_begin < t_end) {
+#pragma unroll
+      for (int u = 0; u < NUNITS; ++u) store_unit(u, Xs, Ys);
+      if (t_begin + 1 < t_end) {
+        int n, d0, h0, w0;
+        tile_origin(t_begin + 1, n, d0, h0, w0);
+        load_tile(t_begin + 1); ld_n = n;
       }
-      store_tile(tile);
-      lap(1);
-      __syncthreads();
-      lap(2);
-      if (tile + 1 < t_end) load_tile(tile + 1);
-      lap(3);
-      mfma_tile();
+    }
+    __syncthreads();
+    lap(0);
+    constexpr int LOAD_AT = NUNITS + 1;      // k-step after which the registers are free again
+    static_assert(LOAD_AT < 32, "staging pieces must fit the k-steps of a tile");
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int cur = (tile - t_begin) & 1;
+      float* Xn = Xs + (cur ^ 1) * C::STAGE;
+      float* Yn = Ys + (cur ^ 1) * C::STAGE;
+      if (tile + 1 < t_end) {
+        const int nxt = min(tile + 2, t_end - 1);     // the last tile is loaded twice (never stored the second time)
+        int n2, d2, h2, w2;
+        tile_origin(nxt, n2, d2, h2, w2);
+        mfma_tile(cur * C::STAGE, [&](int s) {
+          if (s < NUNITS) store_unit(s, Xn, Yn);
+          if (s == LOAD_AT) { load_tile(nxt); ld_n = n2; }
+        });
+      } else {
+        mfma_tile(cur * C::STAGE, no_filler);
+      }
       lap(4);
       __syncthreads();
       lap(5);
@@ -362,7 +411,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
       Ys[m * YS + t] = ok ? o : 0.f;
     }
     __syncthreads();
-    mfma_tile();
+    mfma_tile(0, no_filler);
     __syncthreads();
   }
   }

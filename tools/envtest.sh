@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for e in "X=1" "AMD_DIRECT_DISPATCH=0" "X=1" "AMD_DIRECT_DISPATCH=0"; do
-  echo "== $e"; env $e python tools/phase_times.py 2>&1 | tail -1
+export ALL_CLASSES=1
+for e in "X=1" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0" "X=1"; do
+  echo "== $e"; python tools/exp_classes.py "$e" 2>&1
 done
