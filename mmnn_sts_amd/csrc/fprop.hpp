@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     if (tracing) a.trace[(blockIdx.x * (gridDim.z > 1 ? 2 : 1) + (blockIdx.z ? 1 : 0)) % 64 * 16 + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  float pf_sink = 0.f;                                   // keeps the prefetch loads alive (see FpropArgs::pf_ptr)
+  float pf_sink = 0.f, pf_sink2 = 0.f;                   // keep the prefetch loads alive (see FpropArgs::pf_ptr)
   const bool loader = SPEC && tid >= NL;                 // wave-uniform role
   const int ltid = loader ? tid - NL : tid;              // index within the role's thread set
   const int wave = ltid >> 6;
@@ -259,13 +259,14 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     constexpr int W_ITEMS = KC * TAPS * (M_B / 4);
     constexpr int XV_IT = (XV_ITEMS + NL - 1) / NL, XH_IT = (XH_ITEMS + NL - 1) / NL;
     constexpr int W_IT = (W_ITEMS + NL - 1) / NL;
+    static_assert(XV_IT <= 32 && XH_IT <= 32 && W_IT <= 32, "validity bits of the staged items are kept in 32-bit masks");
     constexpr bool GR = (PRO == PRO_GRAD);
     // small tiles (one accumulator per wave) are latency-bound in this loop: keep TWO chunks of loads in flight
     constexpr int PF = (MT * NT == 1) ? 2 : 1;
     struct Stage {
       f32x4 xv0[XV_IT], xv1[GR ? XV_IT : 1], wr[W_IT];
       float xh0[XH_IT > 0 ? XH_IT : 1], xh1[(GR && XH_IT > 0) ? XH_IT : 1];
-      unsigned okv, okh;
+      unsigned okv, okh, okw;
     };
     Stage stA, stB;
 
@@ -286,12 +287,14 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     auto load_w = [&](int c0, Stage& st) {
       const int crem = a.Cin - c0;
       const float* bw = a.w + (long)c0 * TAPS * a.w_ld;
+      unsigned okw = 0;
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
         const bool ok = w_off[i] >= 0 && w_cl[i] < crem;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? bw + w_off[i] : a.w);
-        st.wr[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+        okw |= (ok ? 1u : 0u) << i;
+        st.wr[i] = *reinterpret_cast<const f32x4*>(ok ? bw + w_off[i] : a.w);   // masked when written to LDS: a select on the
+      }                                                                          // loaded value here would wait for the load
+      st.okw = okw;
     };
     // Small tiles: the first chunk's weight loads go out NOW, before the activation descriptors are worked out -- that set-up
     // arithmetic is ~2 us of the small-extent kernels and now overlaps the (always cold) weight fetch.
@@ -361,8 +364,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         const bool ok = xh_off[i] >= 0 && xh_cl[i] < crem;
         const int off = ok ? xh_off[i] : 0;
         okh |= (ok ? 1u : 0u) << i;
-        st.xh0[i] = ok ? b0[off] : in0n[0];
-        if (GR) st.xh1[i] = ok ? b1[off] : in1n[0];
+        st.xh0[i] = *(ok ? b0 + off : in0n);
+        if (GR) st.xh1[i] = *(ok ? b1 + off : in1n);
       }
       st.okv = okv; st.okh = okh;
     };
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 #pragma unroll
       for (int i = 0; i < W_IT; ++i) {
         const int it = ltid + i * NL;
-        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = st.wr[i];
+        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = ((st.okw >> i) & 1u) ? st.wr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     };
 
@@ -400,19 +403,24 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     // big tiles of block 1 amortise the prologue over a long K loop and cannot afford the registers (staging registers live
     // across the fp64 coefficient math: 116 -> 188 VGPRs, one register short of losing the second wave per SIMD).
     if (!EARLY) prologue();
+    // One dword per 128-byte line of the NEXT launch's weights, at most two lines per thread, addresses clamped instead of guarded
+    // and the values consumed only at the very end of the kernel: nothing ever waits for these loads.  Issued after the first
+    // chunk's loads and the coefficient loads (memory returns in order: a cold weight line ahead of them would hold them back).
     auto prefetch_next_weights = [&]() {
-      if (a.pf_ptr == nullptr) return;
+      const unsigned lines = a.pf_bytes >> 7;
+      if (a.pf_ptr == nullptr || lines == 0) return;
       const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      // dispatch order: XCD = lin & 7
       const unsigned per_xcd = (gridDim.x * gridDim.y * gridDim.z + 7u) >> 3;
-      const unsigned lines = a.pf_bytes >> 7;
-      for (unsigned ln = (lin >> 3) * NTHREADS + tid; ln < lines; ln += per_xcd * NTHREADS) pf_sink += a.pf_ptr[(size_t)ln * 32];
+      const unsigned ln0 = (lin >> 3) * NTHREADS + tid, ln1 = ln0 + per_xcd * NTHREADS;
+      pf_sink = a.pf_ptr[(size_t)min(ln0, lines - 1) * 32];
+      pf_sink2 = a.pf_ptr[(size_t)min(ln1, lines - 1) * 32];
     };
     if (SPEC) {
       // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
       if (loader && c_begin < c_end) load_first(stA);
-      prefetch_next_weights();
       stamp(1);
       if (EARLY) prologue();
+      prefetch_next_weights();
       stamp(2);
       if (loader && c_begin < c_end) store_chunk(c_begin, stA, 0);
       __syncthreads();
@@ -428,9 +436,9 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       }
     } else if (PF == 1) {
       if (c_begin < c_end) load_first(stA);
-      prefetch_next_weights();
       stamp(1);
       if (EARLY) prologue();
+      prefetch_next_weights();
       stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += KC) {
         store_chunk(c0, stA);
@@ -443,9 +451,9 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     } else {
       if (c_begin < c_end) load_first(stA);
       if (c_begin + KC < c_end) load_chunk(c_begin + KC, stB);
-      prefetch_next_weights();
       stamp(1);
       if (EARLY) prologue();
+      prefetch_next_weights();
       stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += 2 * KC) {
         store_chunk(c0, stA);
@@ -806,7 +814,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       }
     }
   }
-  if (pf_sink == 1.2345678e-33f) a.out[0] = pf_sink;     // never true in practice: the prefetched values are not used
+  if (pf_sink + pf_sink2 == 1.2345678e-33f) a.out[0] = pf_sink;     // never true in practice: the prefetched values are not used
   stamp(8);
   if (tracing) {
     a.trace[10] = ((unsigned long long)TAPS << 48) | ((unsigned long long)PRO << 40) | ((unsigned long long)EPI << 32) | ((unsigned long long)a.M << 16) | (unsigned long long)a.Cin;

@@ -44,6 +44,16 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
 
 #if defined(__HIPCC__)
 
+#if !defined(MMNN_TRACE_TID)
+#define MMNN_TRACE_TID 0     // thread whose phase stamps a trace build records (developer builds only; 320 = a 4-tap wave of wgrad3)
+#endif
+
+// Pointers read from a device-resident argument table (the batched kernels) are "generic" to the compiler, and every access
+// through them becomes a FLAT instruction -- which counts on the LDS counter (lgkmcnt) as well as on vmcnt, so a wait for an LDS
+// operand inside the MFMA loop also waits for the global loads in flight.  The tile loops therefore load through pointers that
+// are explicitly in the global address space (kernel arguments passed by value get this automatically).
+#define MMNN_GLOBAL __attribute__((address_space(1)))
+
 // ----------------------------------------------------------------------------------------------------------------
 // (r02: a loader / compute wave specialisation of this kernel -- waves 0-3 stage tile t+1 into a second LDS buffer and take one tap,
 // waves 4-7 take 6,6,6,5 taps, one barrier per tile -- measured 10 % SLOWER at 32^3 (1000 vs 905 us for block 1's six layers), 13 %
@@ -213,9 +223,9 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
     auto load_tile = [&](int tile) {
       int n, d0, h0, w0;
       tile_origin(tile, n, d0, h0, w0);
-      const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
-      const float* g0n = a.g0 + (long)n * a.g0_ns + (long)a.g0_coff * V;
-      const float* g1n = a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
+      const MMNN_GLOBAL float* xn = (const MMNN_GLOBAL float*)a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
+      const MMNN_GLOBAL float* g0n = (const MMNN_GLOBAL float*)a.g0 + (long)n * a.g0_ns + (long)a.g0_coff * V;
+      const MMNN_GLOBAL float* g1n = (const MMNN_GLOBAL float*)a.g1 + (long)n * a.g1_ns + (long)a.g1_coff * V;
       const int xbase = ((d0 - 1) * a.H + (h0 - 1)) * a.W + w0;      // tile origin of the halo box (may be negative: only used when in range)
       const int ybase = (d0 * a.H + h0) * a.W + w0;
       okv = okh = oky = 0;
@@ -225,7 +235,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
         const int d = d0 - 1 + ((k >> 8) & 255), h = h0 - 1 + ((k >> 16) & 255), w = w0 + ((k >> 24) & 255);
         const bool ok = k >= 0 && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && w < a.W;
         okv |= (ok ? 1u : 0u) << i;
-        xv[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? xv_s[i] + xbase : 0));
+        xv[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(xn + (ok ? xv_s[i] + xbase : 0));
       }
 #pragma unroll
       for (int i = 0; i < XH_IT; ++i) {
@@ -242,8 +252,8 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
         const bool ok = k >= 0 && d < a.D && h < a.H && w < a.W;
         const int g = ok ? y_s[i] + ybase : 0;
         oky |= (ok ? 1u : 0u) << i;
-        y0[i] = *reinterpret_cast<const f32x4*>(g0n + g);
-        y1[i] = *reinterpret_cast<const f32x4*>(g1n + g);
+        y0[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(g0n + g);
+        y1[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(g1n + g);
       }
     };
     // Tile-invariant coefficients of this thread's items, in registers: the per-tile stores then read nothing from LDS.
@@ -304,7 +314,7 @@ __device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int split,
       }
     };
 #if defined(MMNN_PHASE_TRACE)
-    const bool tracing = a.trace != nullptr && tid == 0 && split < 16 && cg == 0;
+    const bool tracing = a.trace != nullptr && tid == MMNN_TRACE_TID && split < 16 && cg == 0;
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0}, tprev = tracing ? __builtin_amdgcn_s_memtime() : 0;
     auto lap = [&](int k) { if (tracing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr[k] += t - tprev; tprev = t; } };
 #else
@@ -528,9 +538,9 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
     unsigned oka = 0, okb = 0;
     auto load_chunk = [&](int ch) {
       const int n = ch / chunks_per_n, v0 = (ch % chunks_per_n) * VK;
-      const float* xn = a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;
-      const float* g0n = a.g0 + (long)n * a.g0_ns + (long)(a.g0_coff + m0) * V;
-      const float* g1n = a.g1 + (long)n * a.g1_ns + (long)(a.g1_coff + m0) * V;
+      const MMNN_GLOBAL float* xn = (const MMNN_GLOBAL float*)a.x + (long)n * a.x_ns + (long)(a.x_coff + c0) * V;      // (see MMNN_GLOBAL)
+      const MMNN_GLOBAL float* g0n = (const MMNN_GLOBAL float*)a.g0 + (long)n * a.g0_ns + (long)(a.g0_coff + m0) * V;
+      const MMNN_GLOBAL float* g1n = (const MMNN_GLOBAL float*)a.g1 + (long)n * a.g1_ns + (long)(a.g1_coff + m0) * V;
       oka = okb = 0;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
@@ -540,8 +550,8 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
         const bool ok = (it < A_ITEMS) && m0 + m < a.M && v < V;
         const long go = ok ? (long)m * V + v : 0;
         oka |= (ok ? 1u : 0u) << i;
-        ga[i] = *reinterpret_cast<const f32x4*>(g0n + go);
-        gb[i] = *reinterpret_cast<const f32x4*>(g1n + go);
+        ga[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(g0n + go);
+        gb[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(g1n + go);
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
@@ -550,7 +560,7 @@ __device__ __forceinline__ void wgrad1_body(const WgradArgs& a, const int split,
         const int v = v0 + 4 * q;
         const bool ok = (it < B_ITEMS) && c0 + c < a.Cin && v < V;
         okb |= (ok ? 1u : 0u) << i;
-        xb[i] = *reinterpret_cast<const f32x4*>(xn + (ok ? (long)c * V + v : 0));
+        xb[i] = *reinterpret_cast<const MMNN_GLOBAL f32x4*>(xn + (ok ? (long)c * V + v : 0));
       }
     };
     auto store_chunk = [&]() {
