@@ -249,6 +249,53 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     }
   };
 
+  // ---- output positions of this lane, and (MASK_STORE) the epilogue's operand: the pre-activation tensor `ex`, whole tile.  In the
+  // single-slice fast path its loads CAN be issued before the MFMAs of the last chunk (XPRE below): every block of a launch
+  // reaches its epilogue at the same time, and the chip-wide burst of these reads is 40k of a block's 290k cycles in block 1's
+  // data gradient (phase trace r02), matrix pipe idle. ----
+  float* outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
+  const float* exn = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) ? a.ex + (long)n * a.ex_ns + (long)a.ex_coff * V : nullptr;
+  constexpr bool ALL_ROWS = (EPI == EPI_MASK_STORE);
+  float xall[ALL_ROWS ? MT : 1][ALL_ROWS ? 16 : 1][NT];
+  bool xall_loaded = false;
+  auto load_xall = [&]() {
+    if (ALL_ROWS) {
+      int vox[NT];      // (recomputed in the epilogue: kept live across the K loop these cost the small-tile kernels their last registers)
+      bool vok[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int t = (wn * NT + j) * 32 + l31;
+        if (TAPS == 27) {
+          const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+          const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+          vok[j] = d < a.D && h < a.H && w < a.W;
+          vox[j] = (d * a.H + h) * a.W + w;
+        } else {
+          vox[j] = v0_ + t;
+          vok[j] = vox[j] < V;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ml = wm * MT * 32 + i * 32 + acc_row(q, half);
+          const bool mok = (m0 + ml) < a.M;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;   // unconditional loads (clamped)
+            xall[ALL_ROWS ? i : 0][ALL_ROWS ? q : 0][j] = exn[o];
+          }
+        }
+    }
+    xall_loaded = true;
+  };
+  // r02 RESULT: measured SLOWER on the one kernel it targets (block 1's conv2 data gradient 145 -> 167 us: the 64 loads live
+  // across the last chunk push the kernel from 156 to 256 registers), so it is switched off; the smaller tiles have no registers
+  // to spare either.  Kept as a compile-time switch for a version that holds the operand in LDS instead.
+  constexpr bool XPRE = false && ALL_ROWS && TAPS == 27 && TW > 16 && MT * NT > 1 && !SPEC;
+  const bool xall_early = XPRE && gridDim.z == 1 && kg == 0 && !loader;     // wave-uniform
+
   if (vecx && vecw && (long)KC * V < (1l << 30)) {
     // ===== fast path: 16-byte staging through registers, software-pipelined.  The global loads of chunk k+1 are issued
     // (all at once) before the MFMA loop of chunk k and only waited for when they are written to LDS afterwards. =====
@@ -284,6 +331,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       w_off[i] = ok ? kr * a.w_ld + m0 + 4 * q : -1;
       w_cl[i] = kr / TAPS;
     }
+    const bool w_nomask = (a.Cin % KC == 0) && (m0 + M_B <= a.M);   // block-uniform: no padded channel or row in any weight chunk
     auto load_w = [&](int c0, Stage& st) {
       const int crem = a.Cin - c0;
       const float* bw = a.w + (long)c0 * TAPS * a.w_ld;
@@ -392,10 +440,18 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
           Xs[boff + xh_dst[i]] = ((okh >> i) & 1u) ? o : 0.f;
         }
       }
+      if (w_nomask) {   // uniform branch: the selects below are vector instructions, and those come out of the fp32 matrix rate
 #pragma unroll
-      for (int i = 0; i < W_IT; ++i) {
-        const int it = ltid + i * NL;
-        if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = ((st.okw >> i) & 1u) ? st.wr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < W_IT; ++i) {
+          const int it = ltid + i * NL;
+          if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = st.wr[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+          const int it = ltid + i * NL;
+          if (it < W_ITEMS) *reinterpret_cast<f32x4*>(Ws + boff + 4 * it) = ((st.okw >> i) & 1u) ? st.wr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     };
 
@@ -445,6 +501,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         __syncthreads();
         if (c0 == c_begin) stamp(9);
         if (c0 + KC < c_end) load_chunk(c0 + KC, stA);
+        else if (XPRE && xall_early) load_xall();
         mfma_chunk();
         __syncthreads();
       }
@@ -685,8 +742,6 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // ================= epilogue =================
   float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
   float* red1 = red0 + WN * M_B;
-  float* outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
-  const float* exn = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) ? a.ex + (long)n * a.ex_ns + (long)a.ex_coff * V : nullptr;
   const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
 
   int vox[NT];
@@ -713,22 +768,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // budget: the big tiles of block 1 must stay at two waves per SIMD).  Element offsets are 32-bit (host check: M * V < 2^31),
   // so an address costs one register beside the uniform base pointer.
   constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
-  constexpr bool ALL_ROWS = (EPI == EPI_MASK_STORE);
-  float xall[ALL_ROWS ? MT : 1][ALL_ROWS ? 16 : 1][NT];
-  if (ALL_ROWS) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int ml = wm * MT * 32 + i * 32 + acc_row(q, half);
-        const bool mok = (m0 + ml) < a.M;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const unsigned o = (mok && vok[j]) ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vox[j] : 0u;   // unconditional loads (clamped)
-          xall[ALL_ROWS ? i : 0][ALL_ROWS ? q : 0][j] = exn[o];
-        }
-      }
-  }
+  if (ALL_ROWS && !(XPRE && xall_loaded)) load_xall();
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float s0[16], s1[16];
