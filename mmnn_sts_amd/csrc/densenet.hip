@@ -655,10 +655,15 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   struct PendingW { WgradArgs w2, w1; int b, id; };
   std::vector<PendingW> pend;        // consecutive layers in DESCENDING layer id
   static const bool no_batch = [] { const char* e = getenv("MMNN_NO_WGRAD_BATCH"); return e && e[0] == '1'; }();   // debugging aid
+  hipStream_t side_all = side, side2_all = side2;
   auto flush = [&]() -> int {
     if (pend.empty()) return 0;
     int rc2;
-    if (two) {
+    // MMNN_SIDE_FROM_BLOCK=b (with side streams on): only the weight gradients of dense blocks >= b (0-based) leave the main stream
+    static const int side_from = [] { const char* e = getenv("MMNN_SIDE_FROM_BLOCK"); return e ? atoi(e) : 0; }();
+    const bool on_side = two && pend[0].b >= side_from;
+    hipStream_t side = on_side ? side_all : stream, side2 = on_side ? side2_all : stream;
+    if (on_side) {
       hipEvent_t e = next_event();
       MMNN_REQUIRE(e != nullptr, "backward: cannot create a synchronisation event");
       MMNN_HIP(hipEventRecord(e, stream));

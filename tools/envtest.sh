@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export ALL_CLASSES=1
-for e in "X=1" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0" "X=1"; do
-  echo "== $e"; python tools/exp_classes.py "$e" 2>&1
+for e in "X=1" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=2" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=1" "X=1" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=2" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=3"; do
+  echo "== $e"; env $e python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"
 done
