@@ -75,7 +75,12 @@ struct FpropCfg {
   static_assert(KC % 2 == 0 && (KC / 2) % KS == 0, "channel-pair count of a chunk must be a multiple of the K-split");
   static constexpr int STAGE = KC * XS + KC * TAPS * M_B;                       // floats: activations + weights of a chunk
   static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
-  static constexpr int BUF = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
+  static constexpr int BUF0 = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
+  // wide mask epilogue (see fprop_kernel): one 32 x 36 float transposition tile per wave, in the staging area after the K loop
+  static constexpr bool WIDE = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) && KS == 1 && !SPEC;
+  static constexpr int TSTRIDE = 36;
+  static constexpr int TRANS = WIDE ? WM * WN * 32 * TSTRIDE : 0;
+  static constexpr int BUF = BUF0 > TRANS ? BUF0 : TRANS;
   static size_t smem_bytes(int Cin) {
     int cpad = ((Cin + KC - 1) / KC) * KC;
     size_t ncoef = ((size_t)NCOEF * cpad + 3) & ~(size_t)3;   // keep the staging buffers 16-byte aligned
@@ -768,6 +773,98 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // budget: the big tiles of block 1 must stay at two waves per SIMD).  Element offsets are 32-bit (host check: M * V < 2^31),
   // so an address costs one register beside the uniform base pointer.
   constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
+  // Wide form (big tiles, 16-byte aligned tensors): an MFMA accumulator holds ONE voxel per lane and row, so the direct form below
+  // moves 4 bytes per lane and instruction -- 128..192 memory instructions per thread, and the address coalescer, not HBM, bounds
+  // the epilogue (phase trace r02: 33k of a block's 85k cycles in block 1's conv1 data gradient, 40k of 290k in conv2's).  Each
+  // 32 x 32 accumulator tile is therefore transposed through LDS (wave-private, the staging buffers are free) so that a lane holds
+  // 4 consecutive voxels of 4 rows: every global access becomes a dwordx4 -- a quarter of the memory instructions.
+  const bool wide_ok = C::WIDE && (V & 3) == 0 && ((TAPS == 27) ? ((a.W & 3) == 0) : true) && gridDim.z == 1 &&
+                       ((((uintptr_t)outn | (uintptr_t)exn) & 15) == 0);
+  if (C::WIDE && wide_ok) {
+    float* tb = Xs + (wm * WN + wn) * (32 * C::TSTRIDE);
+    const int q4 = 4 * (lane & 7), rl = lane >> 3;            // this lane's voxel quad and first row within a tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x4 vt[NT][4], xq[NT][4], gq[(EPI == EPI_MASK_ACCUM) ? NT : 1][4];
+      unsigned off[NT][4];
+      bool okq[NT][4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        // voxel quad of this lane in tile j
+        const int t = (wn * NT + j) * 32 + q4;
+        int vq; bool vk;
+        if (TAPS == 27) {
+          const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+          const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+          vk = d < a.D && h < a.H && w < a.W;
+          vq = (d * a.H + h) * a.W + w;
+        } else {
+          vq = v0_ + t;
+          vk = vq < V;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();        // the previous tile's reads precede these writes (LDS executes a wave's accesses in order)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[acc_row(r, half) * C::TSTRIDE + l31] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ml = wm * MT * 32 + i * 32 + rl + 8 * k;
+          vt[j][k] = *reinterpret_cast<const f32x4*>(tb + (rl + 8 * k) * C::TSTRIDE + q4);
+          okq[j][k] = vk && (m0 + ml) < a.M;
+          off[j][k] = okq[j][k] ? (unsigned)(m0 + ml) * (unsigned)V + (unsigned)vq : 0u;      // unconditional loads (clamped)
+        }
+      }
+      // all loads of the slab before its stores (see the note on aliasing below)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xq[j][k] = *reinterpret_cast<const f32x4*>(exn + off[j][k]);
+          if (EPI == EPI_MASK_ACCUM) gq[(EPI == EPI_MASK_ACCUM) ? j : 0][k] = *reinterpret_cast<const f32x4*>(outn + off[j][k]);
+        }
+      float s0[4], s1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ml = wm * MT * 32 + i * 32 + rl + 8 * k;
+        const float ea = ecoef[ml], eb = ecoef[M_B + ml], mu = ecoef[2 * M_B + ml], rs = ecoef[3 * M_B + ml], gm = ecoef[4 * M_B + ml];
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (okq[j][k]) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = xq[j][k][e];
+              const float pre = fmaf(ea, x, eb);
+              const float z = pre > 0.f ? vt[j][k][e] : 0.f;
+              const float xh = (x - mu) * rs;
+              t0 += z;
+              t1 += z * xh;
+              o[e] = (EPI == EPI_MASK_STORE) ? z : gq[(EPI == EPI_MASK_ACCUM) ? j : 0][k][e] + gm * z;
+            }
+            *reinterpret_cast<f32x4*>(outn + off[j][k]) = o;
+          }
+        }
+        s0[k] = t0; s1[k] = t1;
+      }
+      if (want_sums) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float r0 = s0[k], r1 = s1[k];
+          r0 += swz_xor<1>(r0); r1 += swz_xor<1>(r1);
+          r0 += swz_xor<2>(r0); r1 += swz_xor<2>(r1);
+          r0 += swz_xor<4>(r0); r1 += swz_xor<4>(r1);
+          if ((lane & 7) == 0) {
+            const int ml = wm * MT * 32 + i * 32 + rl + 8 * k;
+            red0[wn * M_B + ml] = r0;
+            red1[wn * M_B + ml] = r1;
+          }
+        }
+      }
+    }
+  } else {
   if (ALL_ROWS && !(XPRE && xall_loaded)) load_xall();
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -830,6 +927,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         red1[wn * M_B + ml] = r1;
       }
     }
+  }
   }
   }
   stamp(7);
