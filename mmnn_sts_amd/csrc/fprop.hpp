@@ -77,7 +77,7 @@ struct FpropCfg {
   static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
   static constexpr int BUF0 = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
   // wide mask epilogue (see fprop_kernel): one 32 x 36 float transposition tile per wave, in the staging area after the K loop
-  static constexpr bool WIDE = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) && KS == 1 && !SPEC;
+  static constexpr bool WIDE = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) && !SPEC;
   static constexpr int TSTRIDE = 36;
   static constexpr int TRANS = WIDE ? WM * WN * 32 * TSTRIDE : 0;
   static constexpr int BUF = BUF0 > TRANS ? BUF0 : TRANS;
@@ -744,6 +744,9 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   }
 
   stamp(6);
+  // the wide epilogue reuses the staging area: with an in-block K-split the group-0 waves were still reading their partners'
+  // accumulators from it (the cross-block path above has its own barriers)
+  if (C::WIDE && KS > 1 && kz == 1) __syncthreads();
   // ================= epilogue =================
   float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
   float* red1 = red0 + WN * M_B;
@@ -778,8 +781,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // the epilogue (phase trace r02: 33k of a block's 85k cycles in block 1's conv1 data gradient, 40k of 290k in conv2's).  Each
   // 32 x 32 accumulator tile is therefore transposed through LDS (wave-private, the staging buffers are free) so that a lane holds
   // 4 consecutive voxels of 4 rows: every global access becomes a dwordx4 -- a quarter of the memory instructions.
-  const bool wide_ok = C::WIDE && (V & 3) == 0 && ((TAPS == 27) ? ((a.W & 3) == 0) : true) && gridDim.z == 1 &&
-                       ((((uintptr_t)outn | (uintptr_t)exn) & 15) == 0);
+  const bool wide_ok = C::WIDE && (V & 3) == 0 && ((TAPS == 27) ? ((a.W & 3) == 0) : true) && ((((uintptr_t)outn | (uintptr_t)exn) & 15) == 0);
   if (C::WIDE && wide_ok) {
     float* tb = Xs + (wm * WN + wn) * (32 * C::TSTRIDE);
     const int q4 = 4 * (lane & 7), rl = lane >> 3;            // this lane's voxel quad and first row within a tile
