@@ -77,7 +77,7 @@ struct FpropCfg {
   static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
   static constexpr int BUF0 = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
   // wide mask epilogue (see fprop_kernel): one 32 x 36 float transposition tile per wave, in the staging area after the K loop
-  static constexpr bool WIDE = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM) && !SPEC;
+  static constexpr bool WIDE = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM || EPI == EPI_STORE_STATS) && !SPEC;
   static constexpr int TSTRIDE = 36;
   static constexpr int TRANS = WIDE ? WM * WN * 32 * TSTRIDE : 0;
   static constexpr int BUF = BUF0 > TRANS ? BUF0 : TRANS;
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     const int q4 = 4 * (lane & 7), rl = lane >> 3;            // this lane's voxel quad and first row within a tile
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      f32x4 vt[NT][4], xq[NT][4], gq[(EPI == EPI_MASK_ACCUM) ? NT : 1][4];
+      f32x4 vt[NT][4], xq[MASK ? NT : 1][4], gq[(EPI == EPI_MASK_ACCUM) ? NT : 1][4];
       unsigned off[NT][4];
       bool okq[NT][4];
 #pragma unroll
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          xq[j][k] = *reinterpret_cast<const f32x4*>(exn + off[j][k]);
+          if (MASK) xq[MASK ? j : 0][k] = *reinterpret_cast<const f32x4*>(exn + off[j][k]);
           if (EPI == EPI_MASK_ACCUM) gq[(EPI == EPI_MASK_ACCUM) ? j : 0][k] = *reinterpret_cast<const f32x4*>(outn + off[j][k]);
         }
       float s0[4], s1[4];
@@ -831,6 +831,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       for (int k = 0; k < 4; ++k) {
         const int ml = wm * MT * 32 + i * 32 + rl + 8 * k;
         const float ea = ecoef[ml], eb = ecoef[M_B + ml], mu = ecoef[2 * M_B + ml], rs = ecoef[3 * M_B + ml], gm = ecoef[4 * M_B + ml];
+        const float ds = ecoef[5 * M_B + ml];
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -838,13 +839,20 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float x = xq[j][k][e];
-              const float pre = fmaf(ea, x, eb);
-              const float z = pre > 0.f ? vt[j][k][e] : 0.f;
-              const float xh = (x - mu) * rs;
-              t0 += z;
-              t1 += z * xh;
-              o[e] = (EPI == EPI_MASK_STORE) ? z : gq[(EPI == EPI_MASK_ACCUM) ? j : 0][k][e] + gm * z;
+              if (MASK) {
+                const float x = xq[MASK ? j : 0][k][e];
+                const float pre = fmaf(ea, x, eb);
+                const float z = pre > 0.f ? vt[j][k][e] : 0.f;
+                const float xh = (x - mu) * rs;
+                t0 += z;
+                t1 += z * xh;
+                o[e] = (EPI == EPI_MASK_STORE) ? z : gq[(EPI == EPI_MASK_ACCUM) ? j : 0][k][e] + gm * z;
+              } else {     // EPI_STORE_STATS: channel dropout scale, sums for the consumer's batch statistics
+                const float val = vt[j][k][e] * ds;
+                t0 += val;
+                t1 += val * val;
+                o[e] = val;
+              }
             }
             *reinterpret_cast<f32x4*>(outn + off[j][k]) = o;
           }
