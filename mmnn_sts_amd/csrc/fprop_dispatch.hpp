@@ -67,6 +67,7 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
     // Tried and measured no better at 32^3 (r02, tools/exp_classes.py): 8 compute waves with an in-block K-split instead of
     // loader waves (141 vs 140 us), 128-voxel tiles for two blocks per CU (172 us).
     if (a.W > 16) return launch_cfg<27, PRO, EPI, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>(a, s);
+    // (r02: loader waves + two LDS buffers for the 16^3 tile as well -- <1, 2, 2, 1, 1, 8, 1, 4, 16, true> -- measured slower: 36 vs 31 us.)
     if (a.W > 8) return launch_cfg<27, PRO, EPI, 1, 2, 4, 1, 1, 16, 1, 4, 16>(a, s);
     if (a.W > 4) return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 1, 4, 8>(a, s);
     return launch_cfg<27, PRO, EPI, 1, 1, 8, 1, 1, 16, 2, 4, 4>(a, s);

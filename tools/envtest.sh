@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for e in "X=1" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=2" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=1" "X=1" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=2" "MMNN_SIDE_STREAMS=1 MMNN_SIDE_FROM_BLOCK=3"; do
-  echo "== $e"; env $e python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"
+export PICK=conv2_fwd.b2,conv2_dgrad.b2,conv2_fwd.b1,conv1_fwd.b2,stem_conv
+timeout -k 10 400 python -m pytest tests/test_backbone_gpu.py tests/test_ops_gpu.py -m gpu -x -q 2>&1 | tail -3
+for e in "X=1" "X=1"; do
+  python tools/exp_classes.py "$e"
 done
