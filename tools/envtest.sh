@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export PICK=conv2_fwd.b2,conv2_dgrad.b2,conv2_fwd.b1,conv1_fwd.b2,stem_conv
-timeout -k 10 400 python -m pytest tests/test_backbone_gpu.py tests/test_ops_gpu.py -m gpu -x -q 2>&1 | tail -3
-for e in "X=1" "X=1"; do
+export PICK=conv2_wgrad.b1,conv2_wgrad.b2,conv2_wgrad.b3,stem_wgrad
+for e in "X=1" "MMNN_WG3_SPLIT_CAP=10" "MMNN_WG3_SPLIT_CAP=16" "MMNN_WG3_SPLIT_CAP=128" "X=1"; do
   python tools/exp_classes.py "$e"
 done
