@@ -34,9 +34,10 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
   const int wc = wg1_wc(Cin);
   // Each block owns a (128 x 32*wc) tile of the weight gradient and loops over its share of the 64-voxel chunks.  The kernel is
   // HBM-heavy at block 1 (every (layer, channel group) pair re-reads the 128-row dOut operand: ~0.9 GB per launch), so what
-  // matters is balance: ~1536 equal blocks per launch = three rounds of two blocks per CU measured best (r02: 346 / 312 / 279 /
-  // 273 / 296 us at 512 / 768 / 1536 / 2048 / 3072), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
-  static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
+  // matters is balance: ~2048 equal blocks per launch = four rounds of two blocks per CU measured best (r02, after the loads left
+  // the FLAT path: 317 / 281 / 266 / 295 us at 1024 / 1536 / 2048 / 3072; step 8.84 / 8.81 / 8.79 / 8.85 ms including the larger
+  // reduction), bounded by the slab the reduction kernel then has to read (64 MiB per layer).
+  static const int target = [] { const char* e = getenv("MMNN_WG1_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
   const long groups = (long)cdiv(Cin, 32 * wc) * cdiv(M, 128);
   // batch > 1: the number of (layer, channel group) pairs that share the launch -- every block of the launch then gets the same
   // number of chunks, whatever its layer's channel count
