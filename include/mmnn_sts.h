@@ -62,6 +62,17 @@ int mmnn_densenet_forward(void* plan, const float* params, float* runstats, cons
  * training forward untouched.  grad_params: flat, same layout as params; accumulate != 0 adds into it. */
 int mmnn_densenet_backward(void* plan, const float* params, const float* x, void* workspace, const float* grad_out,
                            float* grad_params, int32_t accumulate, uint64_t seed, void* stream);
+/* The same backward cut at dense-block boundaries, for data parallelism (there is no counterpart upstream: main.py:336 is single
+ * process; the accumulate-then-step rule it implements is main.py:403-407,478-481): runs dense blocks hi_block, hi_block-1, ...,
+ * lo_block (0-based).  Calls must walk the blocks downwards without gaps, the first one starting at the last block; the call with
+ * lo_block == 0 also runs the stem.  When a call has completed in stream order, the gradients of every parameter of the blocks it
+ * covered (and of the transition / norm5 behind each, and of the stem when lo_block == 0) are final in grad_params, so their SUM
+ * all-reduce can run while the next call's kernels execute.  mmnn_densenet_backward == one call with (num_blocks-1, 0). */
+int mmnn_densenet_backward_range(void* plan, const float* params, const float* x, void* workspace, const float* grad_out,
+                                 float* grad_params, int32_t accumulate, uint64_t seed, int32_t hi_block, int32_t lo_block, void* stream);
+/* [begin, end) of the flat parameter / gradient buffer owned by dense block `block` (its layers + the transition or norm5 that
+ * follows it); block -1: the stem (conv0, norm0).  The ranges tile [0, param_count) in the order stem, block 0, block 1, ... */
+int mmnn_densenet_block_param_range(const void* plan, int32_t block, int64_t* begin, int64_t* end);
 /* introspection: the ReLU decisions (a*x+b > 0, uint8 [n][C][V]) of one BN+ReLU site of the last training forward.
  * kind 0: relu0 (models/densenet.py:201); 1: denselayer relu1 (:77); 2: relu2 (:81); 3: transition relu (:146).
  * Used by the gradient parity tests (ReLU is not differentiable at 0: a reference must take the same branch). */
@@ -75,12 +86,17 @@ int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, in
 int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
 int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches);
-/* plan options.  "side_streams" (0, 1 or 2; default 0): run the weight-gradient kernels of the backward on that many side streams
+/* plan options.  "no_kz" (0/1): never split the channel axis of a small-extent convolution over several workgroups (the tests' reference
+ * for the cross-workgroup hand-off).  "side_streams" (0, 1 or 2; default 0): run the weight-gradient kernels of the backward on that many side streams
  * beside the data-gradient chain instead of on the caller's stream -- same results.  "single_stream" (0/1): force 0 side streams
  * (un-overlapped kernel durations for profiling).  "params_version" (any non-zero
  * number the caller changes whenever it changed a parameter; 0 = unknown, the default): the forward re-packs the weights only
  * when the version, the parameter buffer or the workspace differs from the last packed one. */
 int mmnn_densenet_set_option(void* plan, const char* name, int64_t value);
+/* nn.BatchNorm3d.num_batches_tracked of every BN of the backbone (module order, int64 [runstat_count / 2 channels ... one per BN]): when set
+ * (non-NULL device pointer to `bn_count` int64 values), every training forward adds 1 to each of them in its running-statistics kernel;
+ * NULL (the default) leaves the counters to the caller. */
+int mmnn_densenet_set_batch_counters(void* plan, int64_t* num_batches_tracked, int32_t bn_count);
 /* byte offset of a named workspace region (tests / GradCAM): "x","g","t1","conv0","st_x",... ; -1 if unknown */
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j);
 
@@ -117,6 +133,7 @@ typedef struct {
   float* grad_bias[MMNN_MLP_MAX_LAYERS];
   float* grad_gamma[MMNN_MLP_MAX_LAYERS];
   float* grad_beta[MMNN_MLP_MAX_LAYERS];
+  int64_t* num_batches_tracked[MMNN_MLP_MAX_LAYERS];   /* optional (NULL: not maintained): nn.BatchNorm1d's step counter, +1 per training forward */
 } mmnn_mlp_params;
 int64_t mmnn_mlp_saved_floats(const mmnn_mlp_desc* d);      /* size of `saved` */
 int mmnn_mlp_forward(const mmnn_mlp_desc* d, const mmnn_mlp_params* p, const float* x, float* out, float* saved, void* stream);
@@ -146,6 +163,22 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
  * grad_preds = d loss / d preds.  scratch: 4 * n floats. */
 int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
                         const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream);
+
+/* The same with sort_key / weight in the element type the caller's tensors already have (the reference's datasets produce int64 and
+ * float32, data/ImageDatasets.py:462): no conversion pass.  Every supported type is exact in the kernel's fp64 arithmetic. */
+#define MMNN_DT_F64 0
+#define MMNN_DT_F32 1
+#define MMNN_DT_I64 2
+#define MMNN_DT_I32 3
+#define MMNN_DT_U8 4
+int mmnn_cox_blend_loss_typed(int32_t heads, int32_t n, int32_t c, const float* preds, const void* sort_key, int32_t sort_key_dtype,
+                              const void* weight, int32_t weight_dtype, const float* head_weights, float* loss, float* head_losses,
+                              float* grad_preds, float* scratch, void* stream);
+/* autograd adjoint of (loss, head_losses) wrt preds (main.py:469): grad_preds = grad_saved * dloss[0] + grad_saved[h] * dheads[h] /
+ * head_weights[h], where grad_saved is what mmnn_cox_blend_loss wrote.  dloss (1 float) / dheads ([heads]) are device pointers, either may
+ * be NULL (that output took no part in the graph). */
+int mmnn_cox_blend_backward(int32_t heads, int32_t n, int32_t c, const float* grad_saved, const float* head_weights, const float* dloss,
+                            const float* dheads, float* grad_preds, void* stream);
 
 /* ---- element-wise binary cross entropy on logits with per-class positive weights: nn.BCEWithLogitsLoss(pos_weight=...,
  * reduction='none') of the classification trainer (main.py:147-153), the loss behind `criterion` (utils/utils.py:20-22) and
@@ -189,6 +222,45 @@ int mmnn_gap_fc_sigmoid_backward(int32_t n, int32_t c, int64_t v, int32_t o, con
  * d = g + wd*p; buf = first_step ? d : momentum*buf + d; p -= lr * (nesterov ? d + momentum*buf : buf) */
 int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
                   int32_t nesterov, int32_t first_step, void* stream);
+
+/* The same update for a LIST of small tensors (the ~30 parameter tensors of the MLP, the feature layer and the heads) in ONE launch.
+ * momentum_buf is one flat buffer; tensor i owns [flat_offset, flat_offset + count).  first_step is per tensor (torch creates a
+ * parameter's momentum buffer at its first step WITH a gradient; tensors without gradient are simply not listed). */
+#define MMNN_MULTI_MAX 64
+typedef struct {
+  float* param;            /* may be NULL for mmnn_multi_copy */
+  const float* grad;
+  int64_t count;
+  int64_t flat_offset;     /* position of this tensor inside the flat momentum / bucket buffer (floats) */
+  int32_t first_step;
+  int32_t reserved;
+} mmnn_tensor_ref;
+int mmnn_sgd_step_multi(const mmnn_tensor_ref* refs, int32_t n, float* momentum_buf, float lr, float momentum, float weight_decay,
+                        int32_t nesterov, void* stream);
+/* scatter == 0: flat[flat_offset + i] = grad[i] (gather the small gradients into ONE all-reduce bucket); scatter != 0: the way back */
+int mmnn_multi_copy(const mmnn_tensor_ref* refs, int32_t n, float* flat, int32_t scatter, void* stream);
+
+/* ---- Grad-CAM of the fusion model on the last Conv3d of the image backbone: MultiModalGradCAM.forward after its model forward
+ * (utils/utils.py:293-344), batch size 1 (:334).  Per class, in order: d out[0,cls] / d act in closed form (fused head -> feature_layer ->
+ * average pool -> ReLU mask -> eval-mode norm5 scale, restricted to the captured layer = the LAST `growth` channels of the concat),
+ * channel-pooled gradient (:308-311), the activations weighted by it IN PLACE and therefore cumulatively across classes (:313-314),
+ * channel mean, min-max normalisation (:316-323), trilinear up-sampling to the input extent (:339, align_corners = False). */
+typedef struct {
+  int32_t c_total;          /* channels of the norm5 output */
+  int32_t growth;           /* channels of the captured layer (<= 64) */
+  int32_t d, h, w;          /* extent of the captured activations */
+  int32_t classes;          /* rows of the fused head = Grad-CAM targets (<= 16) */
+  int32_t features;         /* width of DenseNet.features' output = the image half of the fused head's input */
+  int32_t head_ld;          /* row stride (floats) of the fused head weight (2 * features in the fusion model) */
+  int32_t out_d, out_h, out_w;   /* extent of the attention maps = of the input volume */
+  float eps;                /* norm5 eps */
+} mmnn_gradcam_desc;
+/* h5 [c_total][v]: eval-mode norm5 output; act_in [growth][v]: output of the last conv2 (the last channels of the block buffer);
+ * w_head [classes][head_ld]; w_feat [features][c_total]; gamma5 / running_var5 [c_total].
+ * Writes act [growth][v] (the weighted activations after the last class = `.features`), grads [growth][v] (the gradient of the last class
+ * = `.grads`; may be NULL), heat [classes][v] (the normalised low-resolution maps) and maps [classes][out_d][out_h][out_w]. */
+int mmnn_gradcam(const mmnn_gradcam_desc* d, const float* h5, const float* act_in, const float* w_head, const float* w_feat,
+                 const float* gamma5, const float* running_var5, float* act, float* grads, float* heat, float* maps, void* stream);
 
 #ifdef __cplusplus
 }

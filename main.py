@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mmnn_sts_amd import distributed as D  # noqa: E402
-from mmnn_sts_amd.data.constants import CLASSIFICATION_THRESHOLD, NUM_CLASSES, SUPER_BATCH_SIZE  # noqa: E402
+from mmnn_sts_amd.data.constants import CLASSIFICATION_THRESHOLD, NUM_BOOTSTRAP_ITERATIONS, NUM_CLASSES, SUPER_BATCH_SIZE  # noqa: E402
 from mmnn_sts_amd.losses.GradientBlender import GradientBlender  # noqa: E402
 from mmnn_sts_amd.losses.losses import BCEWithLogitsLoss, CoxPH  # noqa: E402
 from mmnn_sts_amd.optim import FusedSGD  # noqa: E402
@@ -110,6 +110,26 @@ def gather_rows(t: torch.Tensor, dim: int, world: int) -> torch.Tensor:
     parts = [torch.empty_like(t) for _ in range(world)]
     torch.distributed.all_gather(parts, t.contiguous())
     return torch.cat(parts, dim=dim)
+
+
+def bootstrap_c_indices(preds, events, durations, iterations: int = NUM_BOOTSTRAP_ITERATIONS, seed: int = 0):
+    """main.py:767-768,857-887 (`--bootstrap`): C-indices of `iterations` resamples (with replacement, same size) of the evaluated
+    patients -> (per-target means, per-target standard deviations, number of usable resamples).  Upstream re-runs the model over every
+    resampled uid list; in eval mode with batch size 1 a patient's prediction does not depend on its neighbours, so resampling the
+    PREDICTIONS of one pass gives the same numbers at 1/50th of the device work.  A resample without any admissible pair is skipped
+    (upstream: `except ZeroDivisionError: continue`, :857-858)."""
+    preds, events, durations = (np.asarray(t) for t in (preds, events, durations))
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(iterations):
+        idx = rng.integers(0, len(preds), len(preds))
+        c = getCIndices(preds[idx], events[idx], durations[idx])
+        if not np.any(np.isnan(c)):
+            rows.append(c)
+    if not rows:
+        return [float("nan")] * NUM_CLASSES, [float("nan")] * NUM_CLASSES, 0
+    arr = np.asarray(rows)
+    return arr.mean(axis=0).tolist(), arr.std(axis=0).tolist(), len(rows)
 
 
 # ---- data plumbing -----------------------------------------------------------------------------------------------------------
@@ -251,14 +271,16 @@ def train_survival(model, train_ds, val_ds, args, device, rank, world):
 
 
 # ---- classification (main.py:125-327) ----------------------------------------------------------------------------------------
-def train_classification(model, train_ds, val_ds, args, device):
+def train_classification(model, train_ds, val_ds, args, device, rank=0, world=1):
     """Binary classification of the event flags: pos-weighted BCE on logits (:147-153), SGD-Nesterov + OneCycleLR stepped every
     batch (:207-215), F1 per class (:217-233,:289-300), best mean validation F1 -> model.pth (:301-306); with --blend the
-    GradientBlender's classification branch (:156,:210,:264,:311-314)."""
+    GradientBlender's classification branch (:156,:210,:264,:311-314).  With `world` > 1 every rank trains on its own patients:
+    identical initial weights, gradients SUM-all-reduced before every optimizer step, checkpoints written by rank 0 only."""
     bs = max(2, args.batch_size)
     loader = torch.utils.data.DataLoader(train_ds, batch_size=bs, shuffle=True, collate_fn=collate, drop_last=len(train_ds) > bs)
     val_loader = torch.utils.data.DataLoader(val_ds, batch_size=bs, shuffle=False, collate_fn=collate)
     model = model.to(device)
+    D.broadcast_parameters(model)
     freqs = torch.tensor(args.class_frequencies, dtype=torch.float32)
     pos_weights = ((torch.ones_like(freqs) - freqs) / freqs).to(device)
     train_loss_function = BCEWithLogitsLoss(pos_weight=pos_weights, reduction='sum')
@@ -278,6 +300,7 @@ def train_classification(model, train_ds, val_ds, args, device):
             outputs = model(x)
             loss = blender.computeLoss(outputs, labels.float()) if args.blend else criterion(train_loss_function, outputs, labels.float(), device)
             loss.backward()
+            D.allreduce_gradients(model)
             opt.step()
             sched.step()
             epoch_loss += loss.detach()
@@ -309,21 +332,29 @@ def train_classification(model, train_ds, val_ds, args, device):
         mean_f1 = float(np.nanmean(f1s)) if not np.all(np.isnan(f1s)) else 0.0
         if mean_f1 > best_metric:
             best_metric, best_epoch = mean_f1, epoch + 1
-            os.makedirs(args.output_path, exist_ok=True)
-            torch.save(model.state_dict(), os.path.join(args.output_path, 'model.pth'))
-            logger.info('saved new best metric model')
-        logger.info(f"epoch {epoch + 1}/{args.epochs} average loss: {float(epoch_loss) / len(train_ds):.4f} train f1 {train_f1:.4f} "
-                    f"validation loss {test_loss / len(val_ds):.4f} current f1: {mean_f1:.4f} best f1: {best_metric:.4f} at epoch: {best_epoch}")
+            if rank == 0:
+                os.makedirs(args.output_path, exist_ok=True)
+                torch.save(model.state_dict(), os.path.join(args.output_path, 'model.pth'))
+                logger.info('saved new best metric model')
+        if rank == 0:
+            logger.info(f"epoch {epoch + 1}/{args.epochs} average loss: {float(epoch_loss) / len(train_ds):.4f} train f1 {train_f1:.4f} "
+                        f"validation loss {test_loss / len(val_ds):.4f} current f1: {mean_f1:.4f} best f1: {best_metric:.4f} at epoch: {best_epoch}")
         if args.blend and blender_update_due(epoch, args.blend_update_interval):
-            blender.updateWeights(torch.cat(train_preds, dim=1), torch.cat(train_gt).float(), torch.cat(val_preds, dim=1), torch.cat(val_gt).float())
-            logger.info('Completed updating gradient blender weights - new weights : {}'.format(blender.weights))
-    torch.save(model.state_dict(), os.path.join(args.output_path, 'final_model.pth'))
+            # as in the survival loop: the training patients of all ranks (the validation set is the same everywhere) -> one weight vector
+            blender.updateWeights(gather_rows(torch.cat(train_preds, dim=1), 1, world), gather_rows(torch.cat(train_gt).float(), 0, world),
+                                  torch.cat(val_preds, dim=1), torch.cat(val_gt).float())
+            if rank == 0:
+                logger.info('Completed updating gradient blender weights - new weights : {}'.format(blender.weights))
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(args.output_path, 'final_model.pth'))
     return model
 
 
 def inference_survival(model, ds, args, device):
     """main.py:750-887: batch-1 loop, Grad-CAM maps (saved as .npy; NIfTI export needs nibabel, host I/O), C-index."""
     model = model.to(device).eval()
+    if args.bootstrap:
+        args.no_gradcam = True                       # main.py:774-777: no attention maps, no prediction dump while bootstrapping
     cam = add_gradcam(model, multimodal=True) if (args.images and args.multimodal and not args.no_gradcam) else None
     preds, evs, dus = [], [], []
     os.makedirs(os.path.join(args.output_path, "attention_maps"), exist_ok=True)
@@ -338,7 +369,12 @@ def inference_survival(model, ds, args, device):
                 p = model(x)
         preds.append(p.cpu()); evs.append(ev); dus.append(du)
     p, e, d = torch.cat(preds).numpy(), torch.cat(evs).numpy(), torch.cat(dus).numpy()
-    logger.info('All C-indexes: {}'.format(getCIndices(p, e, d)))
+    if args.bootstrap:
+        means, stds, used = bootstrap_c_indices(p, e, d)
+        logger.info('Mean c indices: {}'.format(means))
+        logger.info('Std. devs: {} ({} of {} resamples had admissible pairs)'.format(stds, used, NUM_BOOTSTRAP_ITERATIONS))
+    else:
+        logger.info('All C-indexes: {}'.format(getCIndices(p, e, d)))
     return p
 
 
@@ -348,7 +384,7 @@ def build_arg_parser():
                     ("radiomics", "radiomic features (not implemented upstream either)"), ("images", "image data"),
                     ("classification", "binary classification"), ("survival", "time-to-event model"), ("segmentation", "unsupported"),
                     ("lr_finder", "unsupported tooling"), ("no_gradcam", "disable Grad-CAM for inference"), ("inference", "inference"),
-                    ("split", "create a new dataset split"), ("blend", "gradient blending"), ("bootstrap", "bootstrap evaluation")):
+                    ("split", "create a new dataset split"), ("blend", "gradient blending"), ("bootstrap", "bootstrap evaluation (with --inference --survival)")):
         ap.add_argument(f"--{flag}", action="store_true", help=h)
     for twin in ("use_images", "use_preop", "use_postop", "classification_task", "inference_task", "survival_task", "use_blend"):
         ap.add_argument(f"--{twin}", type=str, default="false")
@@ -381,6 +417,8 @@ def main(argv=None):
     assert any([a.classification, a.survival, a.segmentation]), 'Must specify one of --classification , --survival , or --segmentation'
     if a.segmentation or a.lr_finder or a.radiomics:
         raise SystemExit("--segmentation / --lr_finder / --radiomics are outside the MI355X fusion path (SURVEY 2)")
+    if a.bootstrap and not (a.inference and a.survival):
+        raise SystemExit("--bootstrap resamples the evaluation of `--inference --survival` (main.py:767-887); it has no meaning for training runs")
     if a.image_loc:
         raise SystemExit("image loaders (NIfTI / DICOM / S3) are host I/O outside this path; run without --image_loc for synthetic volumes")
 
@@ -412,7 +450,8 @@ def main(argv=None):
         n_train, n_val = max(4, a.synthetic_patients), max(4, a.synthetic_patients // 4)
         train_csv = a.data_loc or write_synthetic_csv(os.path.join(a.output_path, f"synthetic_train_rank{rank}.csv"), n_train, predictors, 1000 + rank)
         val_csv = write_synthetic_csv(os.path.join(a.output_path, f"synthetic_val_rank{rank}.csv"), n_val, predictors, 7)
-        mk = lambda n, seed: ClinicalCsvDataset(train_csv if seed >= 1000 else val_csv, predictors)
+        eval_csv = a.data_loc or val_csv        # --inference --data_loc x.csv evaluates THAT file
+        mk = lambda n, seed: ClinicalCsvDataset(train_csv if seed >= 1000 else (eval_csv if seed == 99 else val_csv), predictors)
     elif a.data_loc:
         raise SystemExit("clinical csv + image loaders are host I/O outside this path; run without --data_loc for synthetic patients")
     if a.inference:
@@ -420,7 +459,7 @@ def main(argv=None):
     elif a.survival:
         train_survival(model, mk(a.synthetic_patients, 1000 + rank), mk(max(2, a.synthetic_patients // 4), 7), a, device, rank, world)
     else:
-        train_classification(model, mk(max(4, a.synthetic_patients), 1000 + rank), mk(max(4, a.synthetic_patients // 4), 7), a, device)
+        train_classification(model, mk(max(4, a.synthetic_patients), 1000 + rank), mk(max(4, a.synthetic_patients // 4), 7), a, device, rank, world)
     if world > 1:
         torch.distributed.destroy_process_group()
 

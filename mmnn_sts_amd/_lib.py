@@ -34,9 +34,25 @@ class MlpDesc(Structure):
     ]
 
 
+MULTI_MAX = 64
+DT_F64, DT_F32, DT_I64, DT_I32, DT_U8 = 0, 1, 2, 3, 4
+
+
+class TensorRef(Structure):
+    """mmnn_tensor_ref: one small tensor of a multi-tensor launch (mmnn_sgd_step_multi / mmnn_multi_copy)."""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("count", c_int64), ("flat_offset", c_int64), ("first_step", c_int32),
+                ("reserved", c_int32)]
+
+
+class GradcamDesc(Structure):
+    _fields_ = [("c_total", c_int32), ("growth", c_int32), ("d", c_int32), ("h", c_int32), ("w", c_int32), ("classes", c_int32),
+                ("features", c_int32), ("head_ld", c_int32), ("out_d", c_int32), ("out_h", c_int32), ("out_w", c_int32), ("eps", c_float)]
+
+
 class MlpParams(Structure):
     _fields_ = [(k, c_void_p * MLP_MAX_LAYERS) for k in (
-        "weight", "bias", "gamma", "beta", "running_mean", "running_var", "grad_weight", "grad_bias", "grad_gamma", "grad_beta")]
+        "weight", "bias", "gamma", "beta", "running_mean", "running_var", "grad_weight", "grad_bias", "grad_gamma", "grad_beta",
+        "num_batches_tracked")]
 
 
 def lib():
@@ -65,6 +81,11 @@ def lib():
     L.mmnn_densenet_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
     L.mmnn_densenet_backward.restype = c_int32
     L.mmnn_densenet_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_void_p]
+    L.mmnn_densenet_backward_range.restype = c_int32
+    L.mmnn_densenet_backward_range.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_int32, c_int32,
+                                               c_void_p]
+    L.mmnn_densenet_block_param_range.restype = c_int32
+    L.mmnn_densenet_block_param_range.argtypes = [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64)]
     L.mmnn_densenet_relu_mask.restype = c_int32
     L.mmnn_densenet_relu_mask.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     L.mmnn_densenet_ws_offset.restype = c_int64
@@ -80,7 +101,12 @@ def lib():
         "mmnn_linear_forward": [I, I, I, V, V, V, V, V],
         "mmnn_linear_backward": [I, I, I, V, V, V, V, V, V, I, V],
         "mmnn_cox_blend_loss": [I, I, I, V, V, V, V, V, V, V, V, V],
+        "mmnn_cox_blend_loss_typed": [I, I, I, V, V, I, V, I, V, V, V, V, V, V],
+        "mmnn_cox_blend_backward": [I, I, I, V, V, V, V, V, V],
         "mmnn_sgd_step": [V, V, V, c_int64, F, F, F, I, I, V],
+        "mmnn_sgd_step_multi": [POINTER(TensorRef), I, V, F, F, F, I, V],
+        "mmnn_multi_copy": [POINTER(TensorRef), I, V, I, V],
+        "mmnn_gradcam": [POINTER(GradcamDesc), V, V, V, V, V, V, V, V, V, V, V],
         "mmnn_bce_logits": [c_int64, I, V, V, V, V, V, V],
         "mmnn_conv3d_out_shape": [POINTER(Conv3dDesc), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)],
         "mmnn_conv3d_forward": [POINTER(Conv3dDesc), V, V, V, V],
@@ -94,6 +120,7 @@ def lib():
         "mmnn_densenet_read_timer": [V, POINTER(ctypes.c_double), POINTER(c_int64)],
         "mmnn_densenet_read_timer_class": [V, I, I, POINTER(ctypes.c_double), POINTER(c_int64)],
         "mmnn_densenet_set_option": [V, c_char_p, c_int64],
+        "mmnn_densenet_set_batch_counters": [V, V, I],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -41,9 +41,11 @@ def _deps_mtime(path, seen=None):
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     trace = os.environ.get("MMNN_PHASE_TRACE") == "1"     # developer build (tools/phase_trace.py): its own objects and library
-    flags = FLAGS + (["-DMMNN_PHASE_TRACE"] if trace else [])
-    OBJ = os.path.join(HERE, "build_trace" if trace else "build")
-    LIB = os.path.join(HERE, "libmmnn_sts_trace.so" if trace else "libmmnn_sts.so")
+    fenced = os.environ.get("MMNN_KZ_FENCED") == "1"      # portable K-split hand-off (csrc/fprop.hpp): its own objects and library
+    flags = FLAGS + (["-DMMNN_PHASE_TRACE"] if trace else []) + (["-DMMNN_KZ_FENCED=1"] if fenced else [])
+    variant = "_trace" if trace else ("_fenced" if fenced else "")
+    OBJ = os.path.join(HERE, "build" + variant)
+    LIB = os.path.join(HERE, f"libmmnn_sts{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
     objs = []

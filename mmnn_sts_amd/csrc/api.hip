@@ -9,7 +9,7 @@ using namespace mmnn;
 
 extern "C" {
 
-int mmnn_version(void) { return 100; }
+int mmnn_version(void) { return 300; }
 const char* mmnn_last_error(void) { return last_error(); }
 
 void* mmnn_densenet_plan_create(const mmnn_densenet_config* cfg, int32_t n, int32_t d, int32_t h, int32_t w) {
@@ -59,6 +59,21 @@ int mmnn_densenet_backward(void* plan, const float* params, const float* x, void
                        static_cast<hipStream_t>(stream));
 }
 
+int mmnn_densenet_backward_range(void* plan, const float* params, const float* x, void* workspace, const float* grad_out,
+                                 float* grad_params, int32_t accumulate, uint64_t seed, int32_t hi_block, int32_t lo_block, void* stream) {
+  MMNN_REQUIRE(plan, "backward_range: null plan");
+  return plan_backward_range(*static_cast<Plan*>(plan), params, x, static_cast<char*>(workspace), grad_out, grad_params, accumulate, seed,
+                             hi_block, lo_block, static_cast<hipStream_t>(stream));
+}
+
+int mmnn_densenet_block_param_range(const void* plan, int32_t block, int64_t* begin, int64_t* end) {
+  MMNN_REQUIRE(plan && begin && end, "block_param_range: null argument");
+  long b = 0, e = 0;
+  const int rc = plan_block_param_range(*static_cast<const Plan*>(plan), block, &b, &e);
+  *begin = b; *end = e;
+  return rc;
+}
+
 int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, int32_t kind, int32_t block, int32_t layer,
                             uint8_t* out, void* stream) {
   MMNN_REQUIRE(plan && out, "relu_mask: null argument");
@@ -88,6 +103,14 @@ int mmnn_densenet_set_option(void* plan, const char* name, int64_t value) {
   return plan_set_option(*static_cast<Plan*>(plan), name, (long)value);
 }
 
+int mmnn_densenet_set_batch_counters(void* plan, int64_t* num_batches_tracked, int32_t bn_count) {
+  MMNN_REQUIRE(plan, "set_batch_counters: null plan");
+  Plan* p = static_cast<Plan*>(plan);
+  MMNN_REQUIRE(num_batches_tracked == nullptr || bn_count == p->n_bn, "set_batch_counters: the backbone has %d batch norms, got %d counters", p->n_bn, bn_count);
+  p->nbt = reinterpret_cast<long long*>(num_batches_tracked); p->nbt_count = num_batches_tracked ? bn_count : 0;
+  return 0;
+}
+
 int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, int32_t j) {
   if (!plan || !name) return -1;
   return plan_ws_offset(*static_cast<const Plan*>(plan), name, i, j);
@@ -96,6 +119,15 @@ int64_t mmnn_densenet_ws_offset(const void* plan, const char* name, int32_t i, i
 int mmnn_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
                   int32_t nesterov, int32_t first_step, void* stream) {
   return launch_sgd(params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, first_step, static_cast<hipStream_t>(stream));
+}
+
+int mmnn_sgd_step_multi(const mmnn_tensor_ref* refs, int32_t n, float* momentum_buf, float lr, float momentum, float weight_decay,
+                        int32_t nesterov, void* stream) {
+  return launch_sgd_multi(refs, n, momentum_buf, lr, momentum, weight_decay, nesterov, static_cast<hipStream_t>(stream));
+}
+
+int mmnn_multi_copy(const mmnn_tensor_ref* refs, int32_t n, float* flat, int32_t scatter, void* stream) {
+  return launch_multi_copy(refs, n, flat, scatter, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -56,6 +56,9 @@ struct StatPtr {
   double* sq;
   int stride;   // channels per replica row
   int off;      // first channel of the tensor inside the row
+  int nrep;     // replicas the writers of this tensor actually use (power of two <= NREP; the others stay zero): the small-extent layers
+                // have a few dozen writer blocks per launch and are latency chains -- their consumers read 1 or 2 replicas instead of 8
+  int pad_;     // explicit: argument tables that embed a StatPtr are compared bytewise (densenet.hip: wg_shadow)
 };
 
 // Forward batch-norm of channel c:  y = a_c*x + b_c  (then ReLU where the layer has one).
@@ -90,10 +93,14 @@ struct DropCfg {
 };
 
 #if defined(__HIPCC__)
-__device__ __forceinline__ double stat_total(const double* base, int stride, int idx) {
+__device__ __forceinline__ double stat_total(const double* base, int stride, int idx, int nrep = NREP) {
   double t = 0.0;
+  if (nrep == NREP) {
 #pragma unroll
-  for (int r = 0; r < NREP; ++r) t += base[(long)r * stride + idx];
+    for (int r = 0; r < NREP; ++r) t += base[(long)r * stride + idx];
+  } else {
+    for (int r = 0; r < nrep; ++r) t += base[(long)r * stride + idx];
+  }
   return t;
 }
 
@@ -110,8 +117,8 @@ __device__ __forceinline__ double rsqrt_var(double v) {
 __device__ __forceinline__ void bn_fwd_coef(const BnFwd& s, int c, float& a, float& b, float& mean_f, float& rstd_f) {
   double mean, var;
   if (s.training) {
-    mean = stat_total(s.st.sum, s.st.stride, s.st.off + c) * s.inv_count;
-    var = stat_total(s.st.sq, s.st.stride, s.st.off + c) * s.inv_count - mean * mean;
+    mean = stat_total(s.st.sum, s.st.stride, s.st.off + c, s.st.nrep) * s.inv_count;
+    var = stat_total(s.st.sq, s.st.stride, s.st.off + c, s.st.nrep) * s.inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
   } else {
     mean = (double)s.rmean[c];
@@ -126,12 +133,12 @@ __device__ __forceinline__ void bn_fwd_coef(const BnFwd& s, int c, float& a, flo
 }
 
 __device__ __forceinline__ void bn_bwd_coef(const BnBwd& s, int c, float& p, float& q, float& r) {
-  double mean = stat_total(s.st.sum, s.st.stride, s.st.off + c) * s.inv_count;
-  double var = stat_total(s.st.sq, s.st.stride, s.st.off + c) * s.inv_count - mean * mean;
+  double mean = stat_total(s.st.sum, s.st.stride, s.st.off + c, s.st.nrep) * s.inv_count;
+  double var = stat_total(s.st.sq, s.st.stride, s.st.off + c, s.st.nrep) * s.inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
   double rstd = rsqrt_var(var + (double)s.eps);
-  double m1 = stat_total(s.s.sum, s.s.stride, s.s.off + c) * s.inv_count;
-  double m2 = stat_total(s.s.sq, s.s.stride, s.s.off + c) * s.inv_count;
+  double m1 = stat_total(s.s.sum, s.s.stride, s.s.off + c, s.s.nrep) * s.inv_count;
+  double m2 = stat_total(s.s.sq, s.s.stride, s.s.off + c, s.s.nrep) * s.inv_count;
   double g = s.gamma ? (double)s.gamma[c] : 1.0;
   p = (float)(g * rstd);
   q = (float)(-g * rstd * rstd * m2);

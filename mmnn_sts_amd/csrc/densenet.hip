@@ -47,6 +47,8 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
     MMNN_REQUIRE(d >= 1 && h >= 1 && w >= 1, "plan: input too small, block %d has no voxels", b + 1);
     p.Db[b] = d; p.Hb[b] = h; p.Wb[b] = w; p.Vb[b] = d * h * w;
     p.cin_b[b] = c;
+    // replicas of the fp64 statistics (StatPtr::nrep): block 0 receives the stem's statistics (always NREP replicas)
+    p.nrep_b[b] = (b == 0 || (long)N * d * h * w >= 32768) ? NREP : ((long)N * d * h * w >= 4096 ? 2 : 1);
     p.ctot_b[b] = c + cfg.block_layers[b] * cfg.growth;
     c = p.ctot_b[b];
     if (b != cfg.nblocks - 1) {
@@ -224,19 +226,21 @@ void plan_free(Plan& p) {
   p.side = p.side2 = nullptr;
 }
 
-static StatPtr statptr(char* ws, size_t o, int C, int off) {
+static StatPtr statptr(char* ws, size_t o, int C, int off, int nrep = NREP) {
   StatPtr s;
   s.sum = reinterpret_cast<double*>(ws + o);
   s.sq = s.sum + (long)NREP * C;
   s.stride = C;
   s.off = off;
+  s.nrep = nrep;
+  s.pad_ = 0;
   return s;
 }
 static float* fptr(char* ws, size_t o) { return reinterpret_cast<float*>(ws + o); }
 
 // capacities travel with the arguments: no process-global state
 static void set_kz(FpropArgs& a, const Plan& p, char* ws) {
-  a.kz_part = fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
+  a.kz_part = p.no_kz ? nullptr : fptr(ws, p.o_kz_part); a.kz_cnt = reinterpret_cast<unsigned*>(ws + p.o_kz_cnt);
   a.kz_part_bytes = KZ_PART_BYTES; a.kz_cnt_entries = KZ_CNT_ENTRIES;
   // developer aid: every convolution launch gets its own 64 x 16 slot of the phase-trace buffer, in launch order
   a.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;
@@ -385,6 +389,7 @@ int plan_set_option(Plan& p, const char* name, long value) {
   if (s == "trace_buffer") { p.trace_base = reinterpret_cast<unsigned long long*>(value); p.trace_seq = 0; return 0; }   // device pointer, 0 = off
   if (s == "trace_slots") { p.trace_slots = (int)value; return 0; }
   if (s == "params_version") { p.params_version = value; return 0; }
+  if (s == "no_kz") { p.no_kz = value != 0; return 0; }
   set_error("set_option: unknown option '%s'", s.c_str());
   return 1;
 }
@@ -452,7 +457,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
     q.bn = bnfwd(p, statptr(ws, p.o_st_conv0, c.init_features, 0), params, run, p.p_n0w, p.p_n0b, p.r_n0m, p.r_n0v, cnt0, training);
     q.out = fptr(ws, p.o_x[0]); q.out_ns = (long)p.ctot_b[0] * p.Vb[0];
     q.idx = reinterpret_cast<unsigned char*>(ws + p.o_idx);
-    q.st_out = statptr(ws, p.o_st_x[0], p.ctot_b[0], 0);
+    q.st_out = statptr(ws, p.o_st_x[0], p.ctot_b[0], 0, p.nrep_b[0]);
     if (!training) q.st_out.sum = nullptr;
     if ((rc = launch_stem_pool(q, stream))) return rc;
   }
@@ -468,12 +473,12 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
       // conv1: ReLU(BN(concat)) -> T1
-      a.Cin = lo.cin; a.M = p.mid;
+      a.Cin = lo.cin; a.M = p.mid; a.nrep = p.nrep_b[b];
       a.in0 = fptr(ws, p.o_x[b]); a.in0_ns = xns; a.in0_coff = 0;
-      a.bn_in = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, training);
+      a.bn_in = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, training);
       a.w = fptr(ws, p.o_pk_c1[b][l]); a.w_ld = p.mid;
       a.out = fptr(ws, p.o_t1[b][l]); a.out_ns = (long)p.mid * p.Vb[b]; a.out_coff = 0;
-      a.st_out = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
+      a.st_out = statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]);
       if (!training) a.st_out.sum = nullptr;
       a.pf_ptr = fptr(ws, p.o_pk_c2f[b][l]); a.pf_bytes = (unsigned)(sizeof(float) * c.growth * p.mid * 27);
       { ScopedTimer t(p, T_CONV1_FWD, b, stream); rc = launch_fprop(a, 1, PRO_BNRELU, EPI_STORE_STATS, stream); }
@@ -483,13 +488,13 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       memset(&e, 0, sizeof(e));
       set_kz(e, p, ws);
       e.N = N; e.D = p.Db[b]; e.H = p.Hb[b]; e.W = p.Wb[b];
-      e.Cin = p.mid; e.M = c.growth;
+      e.Cin = p.mid; e.M = c.growth; e.nrep = p.nrep_b[b];
       e.in0 = fptr(ws, p.o_t1[b][l]); e.in0_ns = (long)p.mid * p.Vb[b]; e.in0_coff = 0;
-      e.bn_in = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, training);
+      e.bn_in = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, training);
       e.w = fptr(ws, p.o_pk_c2f[b][l]); e.w_ld = c.growth;
       e.out = fptr(ws, p.o_x[b]); e.out_ns = xns; e.out_coff = lo.cin;
       e.drop_out = dropcfg(p, seed, layer_id, training);
-      e.st_out = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);
+      e.st_out = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin, p.nrep_b[b]);
       if (!training) e.st_out.sum = nullptr;
       if (l + 1 < c.block_layers[b]) {
         e.pf_ptr = fptr(ws, p.o_pk_c1[b][l + 1]); e.pf_bytes = (unsigned)(sizeof(float) * p.mid * p.layers[b][l + 1].cin);
@@ -504,18 +509,18 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       PoolFwdArgs q;
       q.N = N; q.C = t.cin; q.D = p.Db[b]; q.H = p.Hb[b]; q.W = p.Wb[b];
       q.x = fptr(ws, p.o_x[b]); q.x_ns = xns;
-      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, t.nw, t.nb, t.rm, t.rv, cnt, training);
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, t.nw, t.nb, t.rm, t.rv, cnt, training);
       q.out = fptr(ws, p.o_ap[b]);
       if ((rc = launch_bnrelu_avgpool(q, stream))) return rc;
       FpropArgs a;
       memset(&a, 0, sizeof(a));
       set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b + 1]; a.H = p.Hb[b + 1]; a.W = p.Wb[b + 1];
-      a.Cin = t.cin; a.M = t.cout;
+      a.Cin = t.cin; a.M = t.cout; a.nrep = p.nrep_b[b + 1];
       a.in0 = fptr(ws, p.o_ap[b]); a.in0_ns = (long)t.cin * p.Vb[b + 1]; a.in0_coff = 0;
       a.w = fptr(ws, p.o_pk_tr[b]); a.w_ld = t.cout;
       a.out = fptr(ws, p.o_x[b + 1]); a.out_ns = (long)p.ctot_b[b + 1] * p.Vb[b + 1]; a.out_coff = 0;
-      a.st_out = statptr(ws, p.o_st_x[b + 1], p.ctot_b[b + 1], 0);
+      a.st_out = statptr(ws, p.o_st_x[b + 1], p.ctot_b[b + 1], 0, p.nrep_b[b + 1]);
       if (!training) a.st_out.sum = nullptr;
       a.pf_ptr = fptr(ws, p.o_pk_c1[b + 1][0]); a.pf_bytes = (unsigned)(sizeof(float) * p.mid * p.layers[b + 1][0].cin);
       if ((rc = launch_fprop(a, 1, PRO_NONE, EPI_STORE_STATS, stream))) return rc;
@@ -523,13 +528,14 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
       BnApplyArgs q;
       q.N = N; q.C = p.ctot_b[b]; q.V = p.Vb[b];
       q.x = fptr(ws, p.o_x[b]); q.x_ns = xns;
-      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, cnt, training);
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, cnt, training);
       q.out = out;
       if ((rc = launch_bn_apply(q, stream))) return rc;
     }
   }
   if (training) {
-    if ((rc = launch_running_stats(reinterpret_cast<const RunStatJob*>(ws + p.o_jobs_run), p.n_run_jobs, c.momentum, stream))) return rc;
+    if ((rc = launch_running_stats(reinterpret_cast<const RunStatJob*>(ws + p.o_jobs_run), p.n_run_jobs, c.momentum,
+                                   p.nbt_count == p.n_run_jobs ? p.nbt : nullptr, stream))) return rc;
   }
   lap(5);
   if (host_timing && ++ht_n % 20 == 0) {
@@ -548,17 +554,17 @@ static void layer_wgrad_args(const Plan& p, const float* params, float* run, cha
   const double cnt = (double)N * p.Vb[b];
   const long xns = (long)p.ctot_b[b] * p.Vb[b], tns = (long)p.mid * p.Vb[b];
   const LayerOff& lo = p.layers[b][l];
-  const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
-  const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
-  const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0);
+  const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+  const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+  const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0, p.nrep_b[b]);
   float* dz2 = fptr(ws, p.o_dz2[b]) + (long)l * N * tns;
   memset(&w2, 0, sizeof(w2));
   w2.N = N; w2.D = p.Db[b]; w2.H = p.Hb[b]; w2.W = p.Wb[b];
   w2.M = c.growth; w2.Cin = p.mid;
   w2.g0 = fptr(ws, p.o_g[b]); w2.g0_ns = xns; w2.g0_coff = lo.cin;
   w2.g1 = fptr(ws, p.o_x[b]); w2.g1_ns = xns; w2.g1_coff = lo.cin;
-  w2.gr.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin);       // BN-backward of the layer's concat slice (gammas folded into G)
-  w2.gr.s = statptr(ws, p.o_s_x[b], p.ctot_b[b], lo.cin);
+  w2.gr.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], lo.cin, p.nrep_b[b]);       // BN-backward of the layer's concat slice (gammas folded into G)
+  w2.gr.s = statptr(ws, p.o_s_x[b], p.ctot_b[b], lo.cin, p.nrep_b[b]);
   w2.gr.gamma = nullptr; w2.gr.inv_count = 1.0 / cnt; w2.gr.eps = c.eps;
   w2.drop.seed = seed; w2.drop.layer = layer_id; w2.drop.p = c.dropout_p;
   w2.x = fptr(ws, p.o_t1[b][l]); w2.x_ns = tns; w2.x_coff = 0;
@@ -569,7 +575,7 @@ static void layer_wgrad_args(const Plan& p, const float* params, float* run, cha
   w1.M = p.mid; w1.Cin = lo.cin;
   w1.g0 = dz2; w1.g0_ns = tns; w1.g0_coff = 0;
   w1.g1 = fptr(ws, p.o_t1[b][l]); w1.g1_ns = tns; w1.g1_coff = 0;
-  w1.gr.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);             // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2
+  w1.gr.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]);             // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2
   w1.gr.s = dg2;
   w1.gr.gamma = params + lo.n2w; w1.gr.inv_count = 1.0 / cnt; w1.gr.eps = c.eps;
   w1.x = fptr(ws, p.o_x[b]); w1.x_ns = xns; w1.x_coff = 0;
@@ -579,14 +585,38 @@ static void layer_wgrad_args(const Plan& p, const float* params, float* run, cha
 
 int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params, int accumulate,
                   uint64_t seed, hipStream_t stream) {
+  return plan_backward_range(p, params, x, ws, grad_out, grad_params, accumulate, seed, p.cfg.nblocks - 1, 0, stream);
+}
+
+int plan_block_param_range(const Plan& p, int block, long* begin, long* end) {
+  const int nb = p.cfg.nblocks;
+  MMNN_REQUIRE(block >= -1 && block < nb && begin && end, "block_param_range: block %d out of range [-1, %d)", block, nb);
+  if (block < 0) { *begin = 0; *end = p.layers[0][0].n1w; return 0; }          // stem: conv0, norm0
+  *begin = p.layers[block][0].n1w;                                              // the block's layers, then its transition / norm5
+  *end = (block + 1 < nb) ? p.layers[block + 1][0].n1w : p.n_params;
+  return 0;
+}
+
+// Backward of dense blocks hi, hi-1, ..., lo (0-based; the whole backward = one call with hi = nblocks-1, lo = 0).  A caller that
+// splits it must walk the blocks downwards without gaps, starting at the last block; the call for `lo == 0` also runs the stem.  When
+// a call returns (in stream order) the gradients of every parameter of blocks [lo, hi] -- plus the stem's when lo == 0 -- are FINAL in
+// grad_params: a data-parallel caller can start reducing that range while the next call's kernels run.
+int plan_backward_range(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params, int accumulate,
+                        uint64_t seed, int hi, int lo, hipStream_t stream) {
   MMNN_REQUIRE(params && x && ws && grad_out && grad_params, "backward: null buffer");
   MMNN_REQUIRE(p.tab_ws == ws && p.tab_params == params, "backward: must follow a training forward on the same buffers");
   const NetCfg& c = p.cfg;
   const int nb = c.nblocks, N = p.N;
+  MMNN_REQUIRE(hi >= lo && lo >= 0 && hi < nb, "backward: bad block range [%d, %d] of %d blocks", lo, hi, nb);
+  MMNN_REQUIRE(hi == nb - 1 || p.bwd_next == hi, "backward: block range [%d, %d] out of order (expected to continue at block %d)", lo, hi, p.bwd_next);
   float* run = p.tab_run;
   int rc;
-  MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
-  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
+  const bool first_call = hi == nb - 1;
+  if (first_call) {
+    MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
+    MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
+  }
+  p.bwd_next = lo - 1;
   // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
   // kernels only consume its products, so they run beside it on `side`, ordered by events.  Matters for the late dense blocks
   // whose kernels fill a fraction of the chip.  Falls back to one stream if the side stream cannot be created.
@@ -631,7 +661,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   // Device-resident argument tables of every layer's two weight-gradient launches (for the batched launches below).  Their
   // content does not depend on the step (the dropout seed travels as a kernel argument), so they are uploaded only when a
   // buffer moved -- in practice once.
-  {
+  if (first_call || !p.wg_uploaded) {
     const size_t bytes = sizeof(WgradArgs) * 2 * p.n_layers;
     if (!p.wg_pinned) {
       MMNN_HIP(hipHostMalloc(&p.wg_pinned, bytes, hipHostMallocDefault));
@@ -705,32 +735,32 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     pend.clear();
     return 0;
   };
-  auto sptr = [&](int b, int off) { return statptr(ws, p.o_s_x[b], p.ctot_b[b], off); };
+  auto sptr = [&](int b, int off) { return statptr(ws, p.o_s_x[b], p.ctot_b[b], off, p.nrep_b[b]); };
   auto concat_grad = [&](int b, int off) {   // BN-backward of concat channels [off, ...) of block b (gammas folded into G)
     BnBwd g;
-    g.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], off);
+    g.st = statptr(ws, p.o_st_x[b], p.ctot_b[b], off, p.nrep_b[b]);
     g.s = sptr(b, off);
     g.gamma = nullptr;
     g.inv_count = 1.0 / ((double)N * p.Vb[b]);
     g.eps = c.eps;
     return g;
   };
-  {  // norm5: first contribution to the last block's G
+  if (first_call) {  // norm5: first contribution to the last block's G
     const int b = nb - 1;
     ConsumerBwdArgs a;
-    a.N = N; a.C = p.ctot_b[b]; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b]; a.mode = 0;
+    a.N = N; a.C = p.ctot_b[b]; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b]; a.mode = 0; a.nrep = p.nrep_b[b];
     a.dy = grad_out;
     a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
-    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, (double)N * p.Vb[b], 1);
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, p.p_n5w, p.p_n5b, p.r_n5m, p.r_n5v, (double)N * p.Vb[b], 1);
     a.g = fptr(ws, p.o_g[b]); a.g_ns = a.x_ns;
-    StatPtr dg = statptr(ws, p.o_dg_n5, p.ctot_b[b], 0);
+    StatPtr dg = statptr(ws, p.o_dg_n5, p.ctot_b[b], 0, p.nrep_b[b]);
     a.dbeta = dg.sum; a.dgamma = dg.sq;
     a.s_acc = sptr(b, 0);
     if ((rc = launch_consumer_bwd(a, stream))) return rc;
   }
   int layer_id = 0;
-  for (int b = 0; b < nb; ++b) layer_id += c.block_layers[b];
-  for (int b = nb - 1; b >= 0; --b) {
+  for (int b = 0; b <= hi; ++b) layer_id += c.block_layers[b];
+  for (int b = hi; b >= lo; --b) {
     const double cnt = (double)N * p.Vb[b];
     const long xns = (long)p.ctot_b[b] * p.Vb[b];
     const long tns = (long)p.mid * p.Vb[b];
@@ -738,17 +768,17 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
     for (int l = c.block_layers[b] - 1; l >= 0; --l) {
       --layer_id;
       const LayerOff& lo = p.layers[b][l];
-      const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
-      const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
-      const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0);
-      const StatPtr dg1 = statptr(ws, p.o_dg_n1[b][l], lo.cin, 0);
+      const BnFwd bn1 = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+      const BnFwd bn2 = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+      const StatPtr dg2 = statptr(ws, p.o_dg_n2[b][l], p.mid, 0, p.nrep_b[b]);
+      const StatPtr dg1 = statptr(ws, p.o_dg_n1[b][l], lo.cin, 0, p.nrep_b[b]);
       const DropCfg drop = dropcfg(p, seed, layer_id, 1);
       // conv2 data gradient -> dZ2 (ReLU mask of norm2 applied) + dgamma2/dbeta2
       FpropArgs a;
       memset(&a, 0, sizeof(a));
       set_kz(a, p, ws);
       a.N = N; a.D = p.Db[b]; a.H = p.Hb[b]; a.W = p.Wb[b];
-      a.Cin = c.growth; a.M = p.mid;
+      a.Cin = c.growth; a.M = p.mid; a.nrep = p.nrep_b[b];
       a.in0 = fptr(ws, p.o_g[b]); a.in0_ns = xns; a.in0_coff = lo.cin;
       a.in1 = fptr(ws, p.o_x[b]); a.in1_ns = xns; a.in1_coff = lo.cin;
       a.gr_in = concat_grad(b, lo.cin);
@@ -768,7 +798,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       w1.trace = (p.trace_base && p.trace_seq < p.trace_slots) ? p.trace_base + (size_t)(p.trace_seq++) * 64 * 16 : nullptr;
       // BN-backward of T1 (single consumer norm2): S1 = dbeta2, S2 = dgamma2, scaled by gamma2
       BnBwd g1;
-      g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0);
+      g1.st = statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]);
       g1.s = dg2;
       g1.gamma = params + lo.n2w;
       g1.inv_count = 1.0 / cnt;
@@ -778,7 +808,7 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       memset(&d, 0, sizeof(d));
       set_kz(d, p, ws);
       d.N = N; d.D = p.Db[b]; d.H = p.Hb[b]; d.W = p.Wb[b];
-      d.Cin = p.mid; d.M = lo.cin;
+      d.Cin = p.mid; d.M = lo.cin; d.nrep = p.nrep_b[b];
       d.in0 = dz2; d.in0_ns = tns; d.in0_coff = 0;
       d.in1 = fptr(ws, p.o_t1[b][l]); d.in1_ns = tns; d.in1_coff = 0;
       d.gr_in = g1;
@@ -837,12 +867,12 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
       if ((rc = launch_fprop(d, 1, PRO_GRAD, EPI_STORE, stream))) return rc;
       // un-pool + ReLU + BN of the transition: first contribution to the previous block's G
       ConsumerBwdArgs q;
-      q.N = N; q.C = t.cin; q.D = p.Db[pb]; q.H = p.Hb[pb]; q.W = p.Wb[pb]; q.mode = 1;
+      q.N = N; q.C = t.cin; q.D = p.Db[pb]; q.H = p.Hb[pb]; q.W = p.Wb[pb]; q.mode = 1; q.nrep = p.nrep_b[pb];
       q.dy = fptr(ws, p.o_dap);
       q.x = fptr(ws, p.o_x[pb]); q.x_ns = pxns;
-      q.bn = bnfwd(p, statptr(ws, p.o_st_x[pb], p.ctot_b[pb], 0), params, run, t.nw, t.nb, t.rm, t.rv, (double)N * p.Vb[pb], 1);
+      q.bn = bnfwd(p, statptr(ws, p.o_st_x[pb], p.ctot_b[pb], 0, p.nrep_b[pb]), params, run, t.nw, t.nb, t.rm, t.rv, (double)N * p.Vb[pb], 1);
       q.g = fptr(ws, p.o_g[pb]); q.g_ns = pxns;
-      StatPtr dg = statptr(ws, p.o_dg_tr[pb], t.cin, 0);
+      StatPtr dg = statptr(ws, p.o_dg_tr[pb], t.cin, 0, p.nrep_b[pb]);
       q.dbeta = dg.sum; q.dgamma = dg.sq;
       q.s_acc = sptr(pb, 0);
       if ((rc = launch_consumer_bwd(q, stream))) return rc;
@@ -876,8 +906,16 @@ int plan_backward(Plan& p, const float* params, const float* x, char* ws, const 
   if ((rc = order(side, stream))) return rc;                // join: every weight-gradient slab is written / reduced
   if (side2 != side && (rc = order(side2, stream))) return rc;
   const long stem_count = (long)c.init_features * c.in_channels * 343;
-  return launch_finalize(reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad), two ? 3 : p.n_grad_jobs, two ? stem_count : p.max_grad,
-                         grad_params, accumulate, stream);
+  const GradJob* jobs = reinterpret_cast<const GradJob*>(ws + p.o_jobs_grad);
+  if (two) {                                                // the blocks' jobs were reduced on the side stream as they became final
+    if (lo > 0) return 0;
+    return launch_finalize(jobs, 3, stem_count, grad_params, accumulate, stream);
+  }
+  // one launch for every job of this call: blocks [lo, hi] (their layers + the transition / norm5 behind them), + the stem when lo == 0
+  const int j0 = lo == 0 ? 0 : p.gj_begin[lo], j1 = p.gj_begin[hi + 1];
+  long jmax = lo == 0 ? stem_count : 0;
+  for (int b = lo; b <= hi; ++b) jmax = std::max(jmax, p.gj_max[b]);
+  return launch_finalize(jobs + j0, j1 - j0, jmax, grad_params, accumulate, stream);
 }
 
 int plan_relu_mask(Plan& p, const float* params, char* ws, int kind, int b, int l, unsigned char* out, hipStream_t stream) {
@@ -899,17 +937,17 @@ int plan_relu_mask(Plan& p, const float* params, char* ws, int kind, int b, int 
     MMNN_REQUIRE(b < c.nblocks - 1, "relu_mask: block %d has no transition", b);
     const TransOff& t = p.trans[b];
     a.C = t.cin; a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
-    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, t.nw, t.nb, t.rm, t.rv, cnt, 1);
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, t.nw, t.nb, t.rm, t.rv, cnt, 1);
     return launch_relu_mask(a, stream);
   }
   MMNN_REQUIRE(l >= 0 && l < c.block_layers[b] && (kind == 1 || kind == 2), "relu_mask: bad site (%d,%d,%d)", kind, b, l);
   const LayerOff& lo = p.layers[b][l];
   if (kind == 1) {
     a.C = lo.cin; a.x = fptr(ws, p.o_x[b]); a.x_ns = (long)p.ctot_b[b] * p.Vb[b];
-    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
+    a.bn = bnfwd(p, statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]), params, run, lo.n1w, lo.n1b, lo.r1m, lo.r1v, cnt, 1);
   } else {
     a.C = p.mid; a.x = fptr(ws, p.o_t1[b][l]); a.x_ns = (long)p.mid * p.Vb[b];
-    a.bn = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
+    a.bn = bnfwd(p, statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]), params, run, lo.n2w, lo.n2b, lo.r2m, lo.r2v, cnt, 1);
   }
   return launch_relu_mask(a, stream);
 }

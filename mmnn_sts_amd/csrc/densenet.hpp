@@ -30,6 +30,7 @@ struct Plan {
   int D0, H0, W0;                         // conv0 output extent
   int Db[MAX_BLOCKS], Hb[MAX_BLOCKS], Wb[MAX_BLOCKS], Vb[MAX_BLOCKS];
   int cin_b[MAX_BLOCKS], ctot_b[MAX_BLOCKS];
+  int nrep_b[MAX_BLOCKS];                 // statistic replicas used by the kernels of a block (StatPtr::nrep)
   int mid;                                // bn_size * growth
   // parameters
   long p_conv0, p_n0w, p_n0b, r_n0m, r_n0v, p_n5w, p_n5b, r_n5m, r_n5v;
@@ -84,6 +85,9 @@ struct Plan {
   int side_streams = 0;                            // option "side_streams": 0 (default), 1 or 2 streams for the weight-gradient kernels
   long params_version = 0, packed_version = 0; const float* packed_params = nullptr; const char* packed_ws = nullptr;   // option "params_version"
   long pack_launches = 0;
+  long long* nbt = nullptr; int nbt_count = 0;     // mmnn_densenet_set_batch_counters
+  bool no_kz = false;                              // option "no_kz": no cross-workgroup K-split (tests)
+  int bwd_next = -1;                               // plan_backward_range: the block the next partial call must start at
   unsigned long long* trace_base = nullptr; mutable int trace_seq = 0; int trace_slots = 0;   // developer aid: per-launch phase stamps
 };
 
@@ -99,6 +103,9 @@ int plan_forward(Plan& p, const float* params, float* runstats, const float* x, 
                  uint64_t seed, hipStream_t stream);
 int plan_backward(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params,
                   int accumulate, uint64_t seed, hipStream_t stream);
+int plan_backward_range(Plan& p, const float* params, const float* x, char* ws, const float* grad_out, float* grad_params,
+                        int accumulate, uint64_t seed, int hi, int lo, hipStream_t stream);
+int plan_block_param_range(const Plan& p, int block, long* begin, long* end);   // block -1: the stem
 long plan_ws_offset(const Plan& p, const char* name, int i, int j);
 // ReLU decisions of one BN+ReLU site after a training forward: kind 0 = relu0 (stem), 1 = layer relu1, 2 = layer relu2,
 // 3 = transition relu.  out: uint8 [N][C][V] of that site.

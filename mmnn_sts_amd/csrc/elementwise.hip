@@ -1,5 +1,7 @@
 #include "elementwise.hpp"
 
+#include <algorithm>
+
 namespace mmnn {
 
 // block-wide sum of two floats -> thread 0 (256 threads)
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(256) consumer_bwd_kernel(const ConsumerBwdArgs
   }
   block_sum2(s0, s1, red);
   if (threadIdx.x == 0) {
-    const int rep = blockIdx.x & (NREP - 1);
+    const int rep = blockIdx.x & ((a.nrep > 0 ? a.nrep : NREP) - 1);
     atomicAdd(a.dbeta + (long)rep * a.C + c, (double)s0);
     atomicAdd(a.dgamma + (long)rep * a.C + c, (double)s1);
     atomicAdd(a.s_acc.sum + (long)rep * a.s_acc.stride + a.s_acc.off + c, (double)gam * s0);
@@ -132,8 +134,9 @@ int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) running_stats_kernel(const RunStatJob* jobs, float momentum) {
+__global__ void __launch_bounds__(256) running_stats_kernel(const RunStatJob* jobs, float momentum, long long* nbt) {
   const RunStatJob j = jobs[blockIdx.x];
+  if (nbt && threadIdx.x == 0) nbt[blockIdx.x] += 1;      // num_batches_tracked of BN number blockIdx.x (jobs are in module order)
   for (int c = threadIdx.x; c < j.C; c += 256) {
     const double mean = stat_total(j.sum, j.stride, j.off + c) / j.count;
     double var = stat_total(j.sq, j.stride, j.off + c) / j.count - mean * mean;
@@ -144,9 +147,9 @@ __global__ void __launch_bounds__(256) running_stats_kernel(const RunStatJob* jo
   }
 }
 
-int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, hipStream_t stream) {
+int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, long long* nbt, hipStream_t stream) {
   if (njobs <= 0) return 0;
-  MMNN_LAUNCH(running_stats_kernel, dim3(njobs), dim3(256), 0, stream, jobs_dev, momentum);
+  MMNN_LAUNCH(running_stats_kernel, dim3(njobs), dim3(256), 0, stream, jobs_dev, momentum, nbt);
   MMNN_HIP(hipGetLastError());
   return 0;
 }
@@ -275,6 +278,70 @@ int launch_sgd(float* p, const float* g, float* buf, long n, float lr, float mom
   int gx = cdiv(n, 1024);
   if (gx > 2048) gx = 2048;
   MMNN_LAUNCH(sgd_kernel, dim3(gx), dim3(256), 0, stream, p, g, buf, n, lr, momentum, weight_decay, nesterov, first_step);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the same update over a LIST of small tensors (the ~30 parameter tensors outside the backbone) in one launch: the table travels
+// as a kernel argument (no upload), blockIdx.y = tensor -------------------------------------------------------------------------------
+struct MultiTable {
+  int n;
+  float* p[MMNN_MULTI_MAX]; const float* g[MMNN_MULTI_MAX]; long count[MMNN_MULTI_MAX]; long off[MMNN_MULTI_MAX]; int first[MMNN_MULTI_MAX];
+};
+
+__global__ void __launch_bounds__(256) sgd_multi_kernel(const MultiTable t, float* buf, float lr, float mom, float wd, int nesterov) {
+  const int k = blockIdx.y;
+  float* p = t.p[k]; const float* g = t.g[k]; float* b = buf + t.off[k];
+  const bool first = t.first[k] != 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.count[k]; i += (long)gridDim.x * 256) {
+    float d = fmaf(wd, p[i], g[i]);
+    const float m = first ? d : fmaf(mom, b[i], d);
+    b[i] = m;
+    d = nesterov ? fmaf(mom, m, d) : m;
+    p[i] = fmaf(-lr, d, p[i]);
+  }
+}
+
+int launch_sgd_multi(const mmnn_tensor_ref* refs, int n, float* buf, float lr, float momentum, float weight_decay, int nesterov, hipStream_t stream) {
+  MMNN_REQUIRE(refs && buf && n >= 1 && n <= MMNN_MULTI_MAX, "sgd_multi: 1..%d tensors per call, got %d", MMNN_MULTI_MAX, n);
+  MultiTable t;
+  t.n = n;
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    MMNN_REQUIRE(refs[i].param && refs[i].grad && refs[i].count > 0 && refs[i].flat_offset >= 0, "sgd_multi: bad tensor %d", i);
+    t.p[i] = refs[i].param; t.g[i] = refs[i].grad; t.count[i] = refs[i].count; t.off[i] = refs[i].flat_offset; t.first[i] = refs[i].first_step;
+    most = std::max(most, (long)refs[i].count);
+  }
+  int gx = cdiv(most, 256);
+  if (gx > 64) gx = 64;
+  MMNN_LAUNCH(sgd_multi_kernel, dim3(gx, n), dim3(256), 0, stream, t, buf, lr, momentum, weight_decay, nesterov);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+// gather (scatter == 0: flat[off_k + i] = grad_k[i]) / scatter (grad_k[i] = flat[off_k + i]) of a list of tensors: the coalesced bucket
+// of the small gradients for the data-parallel all-reduce, without torch.cat / per-tensor copies
+__global__ void __launch_bounds__(256) multi_copy_kernel(const MultiTable t, float* flat, int scatter) {
+  const int k = blockIdx.y;
+  float* g = const_cast<float*>(t.g[k]); float* f = flat + t.off[k];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.count[k]; i += (long)gridDim.x * 256) {
+    if (scatter) g[i] = f[i]; else f[i] = g[i];
+  }
+}
+
+int launch_multi_copy(const mmnn_tensor_ref* refs, int n, float* flat, int scatter, hipStream_t stream) {
+  MMNN_REQUIRE(refs && flat && n >= 1 && n <= MMNN_MULTI_MAX, "multi_copy: 1..%d tensors per call, got %d", MMNN_MULTI_MAX, n);
+  MultiTable t;
+  t.n = n;
+  long most = 0;
+  for (int i = 0; i < n; ++i) {
+    MMNN_REQUIRE(refs[i].grad && refs[i].count > 0 && refs[i].flat_offset >= 0, "multi_copy: bad tensor %d", i);
+    t.p[i] = nullptr; t.g[i] = refs[i].grad; t.count[i] = refs[i].count; t.off[i] = refs[i].flat_offset; t.first[i] = 0;
+    most = std::max(most, (long)refs[i].count);
+  }
+  int gx = cdiv(most, 256);
+  if (gx > 64) gx = 64;
+  MMNN_LAUNCH(multi_copy_kernel, dim3(gx, n), dim3(256), 0, stream, t, flat, scatter);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

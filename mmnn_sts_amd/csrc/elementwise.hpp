@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the DenseNet path: transition pooling, final norm, BN running statistics,
 // weight packing, gradient finalisation.
 #pragma once
+#include "../../include/mmnn_sts.h"
 #include "common.hpp"
 
 namespace mmnn {
@@ -35,6 +36,7 @@ struct ConsumerBwdArgs {
   float* g; long g_ns;
   double* dgamma; double* dbeta;   // [NREP][C]
   StatPtr s_acc;              // S1 / S2 of the block buffer
+  int nrep;                   // replicas the fp64 atomics are spread over (0: NREP)
 };
 int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream);
 
@@ -53,7 +55,7 @@ struct RunStatJob {
   float* rmean; float* rvar;
   double count;
 };
-int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, hipStream_t stream);
+int launch_running_stats(const RunStatJob* jobs_dev, int njobs, float momentum, long long* nbt, hipStream_t stream);   // nbt: optional [njobs] step counters, +1 each
 
 // ---- weight packing (once per forward): dst[k][m] layouts consumed by fprop / stem kernels
 struct PackJob {
@@ -82,5 +84,9 @@ int launch_finalize(const GradJob* jobs_dev, int njobs, long max_count, float* g
 // ---- SGD with momentum / Nesterov / weight decay over a flat buffer (torch.optim.SGD semantics, main.py:410-413)
 int launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay, int nesterov, int first_step,
                hipStream_t stream);
+
+// the same update / a flat gather-scatter over a list of small tensors, one launch each (table passed as a kernel argument)
+int launch_sgd_multi(const mmnn_tensor_ref* refs, int n, float* buf, float lr, float momentum, float weight_decay, int nesterov, hipStream_t stream);
+int launch_multi_copy(const mmnn_tensor_ref* refs, int n, float* flat, int scatter, hipStream_t stream);
 
 }  // namespace mmnn

@@ -18,6 +18,22 @@
 
 namespace mmnn {
 
+// Cross-workgroup K-split hand-off (fprop_kernel, "cross-block K-split").  0: the fence-free form measured valid on gfx950 / ROCm 7.2
+// (MI355X_MICROARCH.md, inter-workgroup visibility, table row "ONE lane of each storing workgroup ... an agent-scope atomic add / the
+// workgroup whose add came last"): partial tiles leave with write-through `sc1` stores, every storing wave drains `vmcnt(0)`, a workgroup
+// barrier, ONE lane's agent-scope ticket; the last arriver reads them with `sc1` loads behind a workgroup barrier.  That is a property of
+// this chip's cache policy, not of the HIP memory model, so it is the default ONLY for gfx950; any other target -- or -DMMNN_KZ_FENCED=1
+// (`MMNN_KZ_FENCED=1 python -m mmnn_sts_amd.build` builds libmmnn_sts_fenced.so) -- gets the portable form: plain stores, an agent-scope
+// RELEASE fence before the ticket, an agent-scope ACQUIRE fence in every reading wave after it.  tests/test_kz_handoff_gpu.py stresses
+// whichever library is loaded; tests/test_host_cpu.py::test_kz_handoff_isa checks that the emitted gfx950 code really carries `sc1`.
+#if !defined(MMNN_KZ_FENCED)
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define MMNN_KZ_FENCED 0
+#else
+#define MMNN_KZ_FENCED 1
+#endif
+#endif
+
 enum Pro { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GRAD = 2 };
 enum Epi { EPI_STORE = 0, EPI_STORE_STATS = 1, EPI_MASK_STORE = 2, EPI_MASK_ACCUM = 3 };
 
@@ -37,6 +53,7 @@ struct FpropArgs {
   BnFwd ebn;
   double* dgamma; double* dbeta;                 // [NREP][M]
   StatPtr s_acc;
+  int nrep;                                      // replicas this launch's epilogue spreads its fp64 atomics over (0: NREP); see StatPtr::nrep
   // cross-block K-split (gridDim.z slices of the channel axis): partial tiles + per-tile arrival counters (zero on entry)
   float* kz_part; unsigned* kz_cnt;
   size_t kz_part_bytes; unsigned kz_cnt_entries;   // capacity of kz_part / kz_cnt as provided by the caller (the split is skipped when it would not fit)
@@ -149,7 +166,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     }
   }
   const int m0 = blockIdx.y * M_B;
-  const int rep = blockIdx.x & (NREP - 1);
+  const int rep = blockIdx.x & ((a.nrep > 0 ? a.nrep : NREP) - 1);
   // channel slice of this block (cross-block K-split): whole chunks [c_begin, c_end)
   const int kz = gridDim.z, nch_all = (a.Cin + KC - 1) / KC;
   const int c_begin = (int)((long)nch_all * blockIdx.z / kz) * KC;
@@ -709,19 +726,35 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            __hip_atomic_store(part + (((long)blockIdx.z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane, acc[i][j][r], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+          for (int r = 0; r < 16; ++r) {
+            float* dst = part + (((long)blockIdx.z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane;
+#if MMNN_KZ_FENCED
+            *dst = acc[i][j][r];
+#else
+            __hip_atomic_store(dst, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_store_dword ... sc1
+#endif
+          }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores before the barrier
     __syncthreads();
     unsigned* ticket = reinterpret_cast<unsigned*>(ecoef + C::ECOEF * M_B);
-    if (tid == 0) *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+#if MMNN_KZ_FENCED
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // cumulative over the barrier: publishes the whole workgroup's stores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler may drop the wait after buffer_wbl2: MI355X_MICROARCH.md, compiler hazard)
+#endif
+      *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     stamp(5);
     const unsigned arrived = *ticket;
     if (arrived != (unsigned)(kz - 1)) return;            // not the last slice of this tile: done
-    if (tid == 0) __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    // Ready for the next launch: nobody else touches this tile's counter any more in THIS launch (all kz slices have arrived), and the
+    // kernel boundary orders the store before the next launch's first add.
+    if (tid == 0) __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if MMNN_KZ_FENCED
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every reading wave: drops this CU's stale L1 lines of the partial tiles
+#endif
     if (kg == 0 && !loader) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -734,8 +767,14 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
             float p0[16], p1[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              p0[r] = __hip_atomic_load(part + (((long)z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              p1[r] = __hip_atomic_load(part + (((long)(z + 1) * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const float* s0 = part + (((long)z * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane;
+              const float* s1 = part + (((long)(z + 1) * NSLOT + slot + i * NT + j) * 16 + r) * 64 + lane;
+#if MMNN_KZ_FENCED
+              p0[r] = *s0; p1[r] = *s1;
+#else
+              p0[r] = __hip_atomic_load(s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              // global_load_dword ... sc1
+              p1[r] = __hip_atomic_load(s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + p0[r]) + p1[r];

@@ -95,7 +95,7 @@ struct MlpArgs {
   int N, nl;
   int din[MLP_MAXL], dout[MLP_MAXL], relu_first[MLP_MAXL];
   const float* w[MLP_MAXL]; const float* b[MLP_MAXL]; const float* gamma[MLP_MAXL]; const float* beta[MLP_MAXL];
-  float* rmean[MLP_MAXL]; float* rvar[MLP_MAXL];
+  float* rmean[MLP_MAXL]; float* rvar[MLP_MAXL]; long long* nbt[MLP_MAXL];
   float* dw[MLP_MAXL]; float* db[MLP_MAXL]; float* dgamma[MLP_MAXL]; float* dbeta[MLP_MAXL];
   const float* x;          // [N][din0]
   float* out;              // [N][dout_last]
@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const MlpArgs a) {
     __syncthreads();
     x = act;
   }
+  if (a.training && tid < a.nl && a.nbt[tid]) *a.nbt[tid] += 1;      // nn.BatchNorm1d.num_batches_tracked
 }
 
 __global__ void __launch_bounds__(256) mlp_bwd_kernel(const MlpArgs a) {
@@ -303,8 +304,8 @@ __global__ void __launch_bounds__(256) heads_bwd_kernel(const HeadsArgs a) {
 struct CoxArgs {
   int H, N, C;
   const float* preds;        // [H][N][C]
-  const double* key;         // [N][C]  (fp64 holds every int64 duration < 2^53 and every fp32 value exactly)
-  const double* wgt;         // [N][C]
+  const void* key; int key_dt;   // [N][C], element type MMNN_DT_*: read as fp64 (holds every int64 duration < 2^53 and every fp32 exactly)
+  const void* wgt; int wgt_dt;   // [N][C]
   const float* hw;           // [H] blend weights (null: all 1)
   float* head_loss;          // [H]  (sum over targets)
   float* loss;               // [1]  sum_h hw[h] * head_loss[h]
@@ -312,6 +313,16 @@ struct CoxArgs {
   float* scratch;            // [4*N]
   float eps;
 };
+
+__device__ __forceinline__ double load_f64(const void* p, int dt, long i) {
+  switch (dt) {
+    case MMNN_DT_F32: return (double)static_cast<const float*>(p)[i];
+    case MMNN_DT_I64: return (double)static_cast<const long long*>(p)[i];
+    case MMNN_DT_I32: return (double)static_cast<const int*>(p)[i];
+    case MMNN_DT_U8: return (double)static_cast<const unsigned char*>(p)[i];
+    default: return static_cast<const double*>(p)[i];
+  }
+}
 
 __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE block: problems in order => reproducible sums
   const int N = a.N, tid = threadIdx.x;
@@ -325,21 +336,21 @@ __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE bl
     int* pos = reinterpret_cast<int*>(cs + N);          // original index of sorted slot
     __syncthreads();
     for (int i = tid; i < N; i += 256) {                // stable descending rank
-      const double ki = a.key[i * a.C + c];
+      const double ki = load_f64(a.key, a.key_dt, i * a.C + c);
       int r = 0;
       for (int j = 0; j < N; ++j) {
-        const double kj = a.key[j * a.C + c];
+        const double kj = load_f64(a.key, a.key_dt, j * a.C + c);
         r += (kj > ki) || (kj == ki && j < i);
       }
       hs[r] = a.preds[((long)h * N + i) * a.C + c];
-      ws[r] = (float)a.wgt[i * a.C + c];
+      ws[r] = (float)load_f64(a.wgt, a.wgt_dt, i * a.C + c);
       pos[r] = i;
     }
     __syncthreads();
     if (tid == 0) {
       float g = -INFINITY;
       double W = 0.0;
-      for (int i = 0; i < N; ++i) { g = fmaxf(g, hs[i]); W += a.wgt[pos[i] * a.C + c]; }
+      for (int i = 0; i < N; ++i) { g = fmaxf(g, hs[i]); W += load_f64(a.wgt, a.wgt_dt, pos[i] * a.C + c); }
       float run = 0.f, num = 0.f;
       for (int i = 0; i < N; ++i) {
         run += expf(hs[i] - g);
@@ -368,6 +379,21 @@ __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE bl
       total += (a.hw ? a.hw[h] : 1.f) * l;
     }
     *a.loss = total;
+  }
+}
+
+// autograd adjoint of the blended loss: out = saved * dloss + saved * dheads[h] / head_weights[h]  (saved = d loss / d preds as written by
+// cox_kernel, i.e. already scaled by head_weights[h]; either upstream gradient may be absent)
+__global__ void __launch_bounds__(256) cox_bwd_kernel(long total, long per_head, const float* saved, const float* hw, const float* dloss,
+                                                      const float* dheads, float* out) {
+  const float dl = dloss ? dloss[0] : 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float f = dl;
+    if (dheads) {
+      const long h = i / per_head;
+      f += dheads[h] / (hw ? hw[h] : 1.f);
+    }
+    out[i] = saved[i] * f;
   }
 }
 
@@ -475,7 +501,7 @@ static int mlp_fill(MlpArgs& a, const mmnn_mlp_desc* d, const mmnn_mlp_params* p
     MMNN_REQUIRE(d->in_dim[i] > 0 && d->out_dim[i] > 0 && (i == 0 || d->in_dim[i] == d->out_dim[i - 1]), "mlp: layer %d dims inconsistent", i);
     a.din[i] = d->in_dim[i]; a.dout[i] = d->out_dim[i]; a.relu_first[i] = d->relu_first[i];
     a.w[i] = p->weight[i]; a.b[i] = p->bias[i]; a.gamma[i] = p->gamma[i]; a.beta[i] = p->beta[i];
-    a.rmean[i] = p->running_mean[i]; a.rvar[i] = p->running_var[i];
+    a.rmean[i] = p->running_mean[i]; a.rvar[i] = p->running_var[i]; a.nbt[i] = reinterpret_cast<long long*>(p->num_batches_tracked[i]);
     a.dw[i] = p->grad_weight[i]; a.db[i] = p->grad_bias[i]; a.dgamma[i] = p->grad_gamma[i]; a.dbeta[i] = p->grad_beta[i];
     MMNN_REQUIRE(a.w[i] && a.b[i] && a.gamma[i] && a.beta[i] && a.rmean[i] && a.rvar[i], "mlp: null parameter pointer in layer %d", i);
   }
@@ -551,16 +577,37 @@ int mmnn_linear_backward(int32_t n, int32_t d, int32_t o, const float* x, const 
   return 0;
 }
 
-int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
-                        const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream) {
+int mmnn_cox_blend_loss_typed(int32_t heads, int32_t n, int32_t c, const float* preds, const void* sort_key, int32_t sort_key_dtype,
+                              const void* weight, int32_t weight_dtype, const float* head_weights, float* loss, float* head_losses,
+                              float* grad_preds, float* scratch, void* stream) {
   MMNN_REQUIRE(heads > 0 && n > 0 && c > 0 && heads * c <= 64 && preds && sort_key && weight && loss && head_losses && grad_preds && scratch,
                "cox_blend_loss: bad arguments (heads*targets must be <= 64)");
+  MMNN_REQUIRE(sort_key_dtype >= MMNN_DT_F64 && sort_key_dtype <= MMNN_DT_U8 && weight_dtype >= MMNN_DT_F64 && weight_dtype <= MMNN_DT_U8,
+               "cox_blend_loss: unknown element type (%d, %d)", sort_key_dtype, weight_dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
   CoxArgs a;
-  a.H = heads; a.N = n; a.C = c; a.preds = preds; a.key = sort_key;
-  a.wgt = weight; a.hw = head_weights; a.head_loss = head_losses; a.loss = loss;
+  a.H = heads; a.N = n; a.C = c; a.preds = preds; a.key = sort_key; a.key_dt = sort_key_dtype;
+  a.wgt = weight; a.wgt_dt = weight_dtype; a.hw = head_weights; a.head_loss = head_losses; a.loss = loss;
   a.grad = grad_preds; a.scratch = scratch; a.eps = 1e-7f;
   MMNN_LAUNCH(cox_kernel, dim3(1), dim3(256), 0, s, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+int mmnn_cox_blend_loss(int32_t heads, int32_t n, int32_t c, const float* preds, const double* sort_key, const double* weight,
+                        const float* head_weights, float* loss, float* head_losses, float* grad_preds, float* scratch, void* stream) {
+  return mmnn_cox_blend_loss_typed(heads, n, c, preds, sort_key, MMNN_DT_F64, weight, MMNN_DT_F64, head_weights, loss, head_losses, grad_preds,
+                                   scratch, stream);
+}
+
+int mmnn_cox_blend_backward(int32_t heads, int32_t n, int32_t c, const float* grad_saved, const float* head_weights, const float* dloss,
+                            const float* dheads, float* grad_preds, void* stream) {
+  MMNN_REQUIRE(heads > 0 && n > 0 && c > 0 && grad_saved && grad_preds && (dloss || dheads), "cox_blend_backward: bad arguments");
+  const long total = (long)heads * n * c;
+  int gx = (int)((total + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  MMNN_LAUNCH(cox_bwd_kernel, dim3(gx), dim3(256), 0, static_cast<hipStream_t>(stream), total, (long)n * c, grad_saved, head_weights, dloss, dheads,
+              grad_preds);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -66,6 +66,7 @@ int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev, int count,
     MMNN_REQUIRE(a.N == f.N && a.D == f.D && a.H == f.H && a.W == f.W && a.M == f.M, "wgrad batch: layer %d differs in extent", i);
     MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "wgrad: non-positive extent");
     MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "wgrad: volume too large for 32-bit voxel indices");
+    MMNN_REQUIRE(taps != 27 || (long)33 * a.D * a.H * a.W < (1l << 31), "wgrad: volume too large for 32-bit element offsets of a 32-channel group");
     MMNN_REQUIRE(a.g0 && a.g1 && a.x && a.slab, "wgrad: null operand");
     MMNN_REQUIRE(a.nsplit >= 1 && a.nsplit <= 65535, "wgrad: bad split count %d", a.nsplit);
     MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");

@@ -73,7 +73,7 @@ class _Backbone(nn.Sequential):
 
     # ---- native state: flat buffers + launch plans.  Owned by exactly ONE module object -------------------------------
     _NATIVE_STATE = ("_flat", "_flat_run", "_flat_nbt", "_flat_grad", "_plans", "_anchor", "_params", "_bns", "_fwd_token",
-                     "_grads_attached", "_grads_stale", "_explicit_version")
+                     "_grads_attached", "_grads_stale", "_explicit_version", "_grad_ready_hook")
 
     #: "always": the weights are re-packed for the kernels on every forward (safe with any way of writing parameters).
     #: "versioned": re-pack only when a parameter changed, as told by the autograd version counters of the parameters (every
@@ -95,6 +95,32 @@ class _Backbone(nn.Sequential):
         object.__setattr__(self, "_grads_attached", False)
         object.__setattr__(self, "_grads_stale", True)
         object.__setattr__(self, "_explicit_version", 1)
+        object.__setattr__(self, "_grad_ready_hook", None)
+
+    def set_grad_ready_hook(self, hook) -> None:
+        """`hook(backbone, begin, end)` (or None): called from inside backward(), in stream order, as soon as the gradients
+        `flat_grad[begin:end]` of this backward are final -- block 4 + norm5 first, then block 3 + its transition, ..., finally block 1 +
+        transition 1 + stem.  With a hook installed the backward runs one C-ABI call per dense block
+        (`mmnn_densenet_backward_range`), so a data-parallel caller can start the all-reduce of a range while the kernels of the
+        next block run (mmnn_sts_amd/distributed.py: OverlappedGradientReducer).  Same kernels, same order, same results."""
+        object.__setattr__(self, "_grad_ready_hook", hook)
+
+    def block_param_ranges(self, ent):
+        """[(begin, end)] of the flat buffers in backward completion order: last block first; the first block's range includes the stem."""
+        r = ent.get("ranges")
+        if r is None:
+            L = _lib.lib()
+            nb = len(self.cfg["block_config"])
+            b, e = ctypes.c_int64(), ctypes.c_int64()
+            r = []
+            for blk in range(nb - 1, -1, -1):
+                _lib.check(L.mmnn_densenet_block_param_range(ent["plan"], blk, ctypes.byref(b), ctypes.byref(e)), "block_param_range")
+                r.append([blk, b.value, e.value])
+            _lib.check(L.mmnn_densenet_block_param_range(ent["plan"], -1, ctypes.byref(b), ctypes.byref(e)), "block_param_range")
+            assert e.value == r[-1][1] and b.value == 0
+            r[-1][1] = 0                                   # the call for block 0 also finishes the stem
+            r = ent["ranges"] = [tuple(t) for t in r]
+        return r
 
     def mark_params_changed(self) -> None:
         """Tell the backbone that parameter values were written behind autograd's back (raw pointers, `p.data`)."""
@@ -190,9 +216,12 @@ class _Backbone(nn.Sequential):
             return ent
         L = _lib.lib()
         c = self.cfg
+        if self.norm0.momentum is None:
+            raise NotImplementedError("BatchNorm3d(momentum=None) (cumulative moving average) is not available in the fused backbone; "
+                                      "the reference builds its norms with the default momentum 0.1 (models/densenet.py:198)")
         bc = list(c["block_config"]) + [0] * (8 - len(c["block_config"]))
         ccfg = _lib.DenseNetConfig(c["in_channels"], c["init_features"], c["growth_rate"], c["bn_size"], len(c["block_config"]),
-                                   (ctypes.c_int32 * 8)(*bc), self.norm0.eps, self.norm0.momentum or 0.1, c["dropout_prob"])
+                                   (ctypes.c_int32 * 8)(*bc), self.norm0.eps, self.norm0.momentum, c["dropout_prob"])
         n, _, d, h, w = x.shape
         plan = L.mmnn_densenet_plan_create(ctypes.byref(ccfg), n, d, h, w)
         if not plan:
@@ -205,7 +234,9 @@ class _Backbone(nn.Sequential):
         ws = torch.empty(L.mmnn_densenet_workspace_bytes(plan), dtype=torch.uint8, device=x.device)
         if os.environ.get("MMNN_POISON_WS") == "1":   # debugging aid: NaN-fill so reads of unwritten workspace words surface
             ws.fill_(255)
-        ent = {"plan": plan, "ws": ws, "out_shape": (n,) + tuple(v.value for v in shp)}
+        # nn.BatchNorm3d.num_batches_tracked: the training forward's running-statistics kernel adds 1 to each (no torch op per step)
+        _lib.check(L.mmnn_densenet_set_batch_counters(plan, self._flat_nbt.data_ptr(), self._flat_nbt.numel()), "set_batch_counters")
+        ent = {"plan": plan, "ws": ws, "out_shape": (n,) + tuple(v.value for v in shp), "nbt_ptr": self._flat_nbt.data_ptr()}
         self._plans[key] = ent
         while len(self._plans) > self._MAX_PLANS:
             _, old = self._plans.popitem(last=False)
@@ -226,6 +257,7 @@ class _Backbone(nn.Sequential):
             raise RuntimeError("mmnn_sts_amd: the DenseNet backbone runs on the MI355X only (no CPU path); move model and input to cuda")
         if x.dim() != 5 or x.shape[1] != self.cfg["in_channels"]:
             raise ValueError(f"expected (N, {self.cfg['in_channels']}, D, H, W) input, got {tuple(x.shape)}")
+        input_needs_grad = x.requires_grad
         x = x.detach()
         x = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
         if not self._storage_ok():
@@ -235,9 +267,11 @@ class _Backbone(nn.Sequential):
         if self.training and torch.is_grad_enabled():
             return _BackboneFn.apply(x, self._anchor, self)
         out = self._run_forward(x, self.training)[0]
-        if torch.is_grad_enabled() and not self.training:
+        if torch.is_grad_enabled() and not self.training and (input_needs_grad or any(p.requires_grad for p in self._params)):
             # eval-mode forward keeps no activations: a later backward() must fail loudly instead of silently producing no
-            # backbone gradients (Grad-CAM has its own closed-form path: utils.MultiModalGradCAM)
+            # backbone gradients (Grad-CAM has its own closed-form path: utils.MultiModalGradCAM).  A fully frozen encoder
+            # (every backbone parameter requires_grad=False, input without grad) has no gradient to produce: its output is a
+            # plain tensor, so heads / MLP / fusion layers can be trained on top of it as with the reference.
             return _NoBackward.apply(out, self._anchor)
         return out
 
@@ -245,6 +279,9 @@ class _Backbone(nn.Sequential):
         ent = self._plan_for(x)
         out = torch.empty(ent["out_shape"], dtype=torch.float32, device=x.device)
         seed = ops.next_seed()
+        if ent["nbt_ptr"] != self._flat_nbt.data_ptr():          # re-flattened since the plan was made
+            _lib.check(_lib.lib().mmnn_densenet_set_batch_counters(ent["plan"], self._flat_nbt.data_ptr(), self._flat_nbt.numel()), "set_batch_counters")
+            ent["nbt_ptr"] = self._flat_nbt.data_ptr()
         version = self._params_version() if self.repack_policy == "versioned" else 0
         if version != ent.get("version", 0):
             _lib.check(_lib.lib().mmnn_densenet_set_option(ent["plan"], b"params_version", version), "set_option")
@@ -252,8 +289,6 @@ class _Backbone(nn.Sequential):
         _lib.check(_lib.lib().mmnn_densenet_forward(ent["plan"], self._flat.data_ptr(), self._flat_run.data_ptr(), x.data_ptr(),
                                                     ent["ws"].data_ptr(), out.data_ptr(), int(training), seed,
                                                     torch.cuda.current_stream().cuda_stream), "mmnn_densenet_forward")
-        if training:
-            self._flat_nbt.add_(1)
         object.__setattr__(self, "_fwd_token", self._fwd_token + 1)
         return out, ent, seed, self._fwd_token
 
@@ -272,9 +307,18 @@ class _Backbone(nn.Sequential):
         # overwrite when nothing is accumulated yet: gradients dropped by zero_grad(set_to_none=True) of any optimizer, or marked
         # stale by FusedSGD.zero_grad() (which keeps the views attached: re-attaching 364 tensors per step costs ~1.5 ms of host time)
         fresh = (not attached) or self._grads_stale
-        _lib.check(_lib.lib().mmnn_densenet_backward(ent["plan"], self._flat.data_ptr(), x.data_ptr(), ent["ws"].data_ptr(),
-                                                     grad_out.data_ptr(), gflat.data_ptr(), 0 if fresh else 1, seed,
-                                                     torch.cuda.current_stream().cuda_stream), "mmnn_densenet_backward")
+        hook = self._grad_ready_hook
+        st = torch.cuda.current_stream().cuda_stream
+        if hook is None:
+            _lib.check(_lib.lib().mmnn_densenet_backward(ent["plan"], self._flat.data_ptr(), x.data_ptr(), ent["ws"].data_ptr(),
+                                                         grad_out.data_ptr(), gflat.data_ptr(), 0 if fresh else 1, seed, st),
+                       "mmnn_densenet_backward")
+        else:
+            for blk, begin, end in self.block_param_ranges(ent):
+                _lib.check(_lib.lib().mmnn_densenet_backward_range(ent["plan"], self._flat.data_ptr(), x.data_ptr(), ent["ws"].data_ptr(),
+                                                                   grad_out.data_ptr(), gflat.data_ptr(), 0 if fresh else 1, seed, blk, blk, st),
+                           "mmnn_densenet_backward_range")
+                hook(self, begin, end)
         if not attached:   # (re)attach .grad views; afterwards gradients accumulate inside the kernel
             off = 0
             for p in params:

@@ -32,11 +32,12 @@ class _Stack(nn.Sequential):
             running += [b.running_mean, b.running_var]
             bns.append(b)
         p = float(getattr(self, f"drop{self._idx[0]}").p)
-        cfg = (self._relu_first, p, bns[0].eps, bns[0].momentum or 0.1, self.training, self._first_id)
-        out = ops.MlpStack.apply(x, cfg, running, *params)
-        if self.training:
-            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
-        return out
+        if bns[0].momentum is None:
+            raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not available in the fused MLP stack; "
+                                      "the reference builds its norms with the default momentum (models/mlp.py:22-48)")
+        counters = [b.num_batches_tracked for b in bns] if x.is_cuda else None      # incremented by the forward kernel itself
+        cfg = (self._relu_first, p, bns[0].eps, bns[0].momentum, self.training, self._first_id, counters)
+        return ops.MlpStack.apply(x, cfg, running, *params)
 
 
 class _Head(nn.Sequential):

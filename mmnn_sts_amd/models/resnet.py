@@ -21,7 +21,9 @@ def _conv(x, conv: nn.Conv3d):
 
 def _bn(x, bn: nn.BatchNorm3d, relu: bool, residual=None, drop_p: float = 0.0):
     training = bn.training
-    out = ops.BatchNormAct3d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.momentum if bn.momentum is not None else 0.1,
+    # momentum=None is torch's cumulative moving average: factor 1 / (batches seen including this one)
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / (int(bn.num_batches_tracked) + 1)
+    out = ops.BatchNormAct3d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, momentum,
                                    bn.eps, training, relu, drop_p if training else 0.0)
     if training:
         bn.num_batches_tracked.add_(1)
@@ -96,26 +98,58 @@ class Bottleneck(nn.Module):
         return _bn(out, self.conv3[1], relu=True, residual=residual, drop_p=drop_p)
 
 
+# (planes, stride) of layer1 .. layer4 (models/resnet.py:134-137) and the width the stem hands to layer1 (:129)
+_STAGE_PLAN = ((8, 1), (16, 2), (8, 2), (16, 2))
+_STEM_WIDTH = 64
+
+
+def _build_stage(block, conv_builder, width_in: int, planes: int, depth: int, stride: int):
+    """One residual stage: `depth` blocks, the first of which may change stride / width and then owns a projection shortcut
+    (1x1x1 conv + BN, models/resnet.py:170-181).  Returns (stage, width_out)."""
+    width_out = planes * block.expansion
+    shortcut = None
+    if stride != 1 or width_in != width_out:
+        shortcut = nn.Sequential(nn.Conv3d(width_in, width_out, kernel_size=1, stride=conv_builder.get_downsample_stride(stride), bias=False),
+                                 nn.BatchNorm3d(width_out))
+    widths = [width_in] + [width_out] * (depth - 1)
+    blocks = [block(w, planes, conv_builder, stride, shortcut) if k == 0 else block(w, planes, conv_builder) for k, w in enumerate(widths)]
+    return nn.Sequential(*blocks), width_out
+
+
+def _init_module(m: nn.Module) -> None:
+    """Initial values per module type (models/resnet.py:186-199)."""
+    if isinstance(m, nn.Conv3d):
+        nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.BatchNorm3d):
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.Linear):
+        nn.init.normal_(m.weight, 0, 0.01)
+        nn.init.zeros_(m.bias)
+
+
 class Resnet18(nn.Module):
     """models/resnet.py:114-199: stem, four stages of `block`s (planes 8 / 16 / 8 / 16, strides 1 / 2 / 2 / 2), element-wise
-    dropout after every stage, global average pool, Linear, sigmoid."""
+    dropout after every stage, global average pool, Linear, sigmoid.  Table-driven: `_STAGE_PLAN` x (conv_makers, layers)."""
 
     def __init__(self, block, conv_makers, layers, stem, num_classes=400, zero_init_residual=False, dropout_prob=0.2):
         super().__init__()
-        self.inplanes = 64
         self.stem = stem()
-        self.dropout = torch.nn.Dropout(p=dropout_prob)
-        self.layer1 = self._make_layer(block, conv_makers[0], 8, layers[0], stride=1)
-        self.layer2 = self._make_layer(block, conv_makers[1], 16, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, conv_makers[2], 8, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, conv_makers[3], 16, layers[3], stride=2)
+        self.dropout = nn.Dropout(p=dropout_prob)
+        width = _STEM_WIDTH
+        for k, ((planes, stride), maker, depth) in enumerate(zip(_STAGE_PLAN, conv_makers, layers), start=1):
+            stage, width = _build_stage(block, maker, width, planes, depth, stride)
+            self.add_module(f"layer{k}", stage)
+        self.inplanes = width                                     # attribute kept for callers that read it
         self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
-        self.fc = nn.Linear(16 * block.expansion, num_classes)
-        self._initialize_weights()
+        self.fc = nn.Linear(width, num_classes)
+        self.apply(_init_module)
         if zero_init_residual:
             for m in self.modules():
                 if isinstance(m, Bottleneck):
-                    nn.init.constant_(m.conv3[1].weight, 0)     # upstream names a non-existent `bn3` here (:147-150)
+                    nn.init.zeros_(m.conv3[1].weight)             # upstream names a non-existent `bn3` here (:147-150)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -128,31 +162,6 @@ class Resnet18(nn.Module):
             for i, blk in enumerate(stage):
                 x = blk(x, drop_p=p if i == len(stage) - 1 else 0.0)     # self.dropout(x) after each stage (:159-166), fused
         return ops.GapFcSigmoid.apply(x, self.fc.weight, self.fc.bias)
-
-    def _make_layer(self, block, conv_builder, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            ds_stride = conv_builder.get_downsample_stride(stride)
-            downsample = nn.Sequential(nn.Conv3d(self.inplanes, planes * block.expansion, kernel_size=1, stride=ds_stride, bias=False),
-                                       nn.BatchNorm3d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, conv_builder, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, conv_builder))
-        return nn.Sequential(*layers)
-
-    def _initialize_weights(self):
-        for m in self.modules():
-            if isinstance(m, nn.Conv3d):
-                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.BatchNorm3d):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.Linear):
-                nn.init.normal_(m.weight, 0, 0.01)
-                nn.init.constant_(m.bias, 0)
 
 
 def r3d_18(num_classes):

@@ -90,7 +90,7 @@ class MlpStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, running, *params):
-        relu_first, p, eps, momentum, training, first_id = cfg
+        relu_first, p, eps, momentum, training, first_id = cfg[:6]
         _need_cuda(x, *params)
         x = _f32c(x)
         nl = len(params) // 4
@@ -108,6 +108,8 @@ class MlpStack(torch.autograd.Function):
         for i in range(nl):
             pp.weight[i], pp.bias[i], pp.gamma[i], pp.beta[i] = (ws[4 * i + j].data_ptr() for j in range(4))
             pp.running_mean[i], pp.running_var[i] = running[2 * i].data_ptr(), running[2 * i + 1].data_ptr()
+            if len(cfg) > 6 and cfg[6] is not None:           # nn.BatchNorm1d.num_batches_tracked, +1 per training forward (in the kernel)
+                pp.num_batches_tracked[i] = cfg[6][i].data_ptr()
         L = _lib.lib()
         saved = torch.empty((max(1, L.mmnn_mlp_saved_floats(ctypes.byref(desc))),), device=x.device, dtype=torch.float32)
         out = torch.empty((n, dims_out[-1]), device=x.device, dtype=torch.float32)
@@ -196,14 +198,14 @@ class FusionHeads(torch.autograd.Function):
         dfi, dfc = torch.empty_like(fi), torch.empty_like(fc)
         dwf = torch.empty_like(wf)
         dbf = torch.empty((c,), device=dev, dtype=torch.float32)
-        dwi, dwc = torch.zeros_like(wi), torch.zeros_like(wc)
-        dbi, dbc = torch.zeros((c,), device=dev, dtype=torch.float32), torch.zeros((c,), device=dev, dtype=torch.float32)
+        # the per-modality heads take part in the graph only with blend (models/multimodal.py:69); the kernel then writes them in full
+        dwi, dwc = (torch.empty_like(wi), torch.empty_like(wc)) if blend else (None, None)
+        dbi, dbc = (torch.empty((c,), device=dev, dtype=torch.float32), torch.empty((c,), device=dev, dtype=torch.float32)) if blend else (None, None)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         _lib.check(_lib.lib().mmnn_fusion_heads_backward(n, f, c, int(blend), fi.data_ptr(), fc.data_ptr(), wf.data_ptr(), wi.data_ptr(),
                                                          wc.data_ptr(), dout.data_ptr(), dfi.data_ptr(), dfc.data_ptr(), dwf.data_ptr(),
-                                                         dbf.data_ptr(), dwi.data_ptr(), dbi.data_ptr(), dwc.data_ptr(), dbc.data_ptr(), 0,
+                                                         dbf.data_ptr(), ptr(dwi), ptr(dbi), ptr(dwc), ptr(dbc), 0,
                                                          _stream()), "fusion_heads_backward")
-        if not blend:   # the per-modality heads do not take part in the graph (models/multimodal.py:69)
-            return dfi, dfc, dwf, dbf, None, None, None, None, None
         return dfi, dfc, dwf, dbf, dwi, dbi, dwc, dbc, None
 
 
@@ -219,31 +221,46 @@ class CoxBlend(torch.autograd.Function):
     def forward(ctx, preds, sort_key, weight, head_weights):
         _need_cuda(preds, sort_key, weight, head_weights)
         preds = _f32c(preds)
-        sort_key = sort_key.to(torch.float64).contiguous()
-        weight = weight.to(torch.float64).contiguous()
+        sort_key, kdt = _cox_operand(sort_key)
+        weight, wdt = _cox_operand(weight)
         h, n, c = preds.shape
         dev = preds.device
         hw = _f32c(head_weights) if head_weights is not None else None
         out = torch.empty((1 + h,), device=dev, dtype=torch.float32)
         grad = torch.empty_like(preds)
         scratch = torch.empty((4 * n,), device=dev, dtype=torch.float32)
-        _lib.check(_lib.lib().mmnn_cox_blend_loss(h, n, c, preds.data_ptr(), sort_key.data_ptr(), weight.data_ptr(),
-                                                  hw.data_ptr() if hw is not None else None, out.data_ptr(), out[1:].data_ptr(),
-                                                  grad.data_ptr(), scratch.data_ptr(), _stream()), "cox_blend_loss")
-        ctx.save_for_backward(grad, hw if hw is not None else torch.ones(h, device=dev))
+        _lib.check(_lib.lib().mmnn_cox_blend_loss_typed(h, n, c, preds.data_ptr(), sort_key.data_ptr(), kdt, weight.data_ptr(), wdt,
+                                                        hw.data_ptr() if hw is not None else None, out.data_ptr(), out[1:].data_ptr(),
+                                                        grad.data_ptr(), scratch.data_ptr(), _stream()), "cox_blend_loss")
+        ctx.save_for_backward(grad, hw)
         ctx.set_materialize_grads(False)     # unused outputs arrive as None instead of zero tensors (no device sync needed)
         return out[0], out[1:]
 
     @staticmethod
     def backward(ctx, dloss, dheads):
         grad, hw = ctx.saved_tensors
-        g = None
-        if dloss is not None:
-            g = grad * dloss
-        if dheads is not None:               # d head_losses[h] / d preds = grad[h] / head_weights[h]
-            t = grad * (dheads / hw).view(-1, 1, 1)
-            g = t if g is None else g + t
+        if dloss is None and dheads is None:
+            return None, None, None, None
+        h, n, c = grad.shape
+        g = torch.empty_like(grad)
+        dl = _f32c(dloss) if dloss is not None else None
+        dh = _f32c(dheads) if dheads is not None else None      # d head_losses[h] / d preds = grad[h] / head_weights[h]
+        _lib.check(_lib.lib().mmnn_cox_blend_backward(h, n, c, grad.data_ptr(), hw.data_ptr() if hw is not None else None,
+                                                      dl.data_ptr() if dl is not None else None, dh.data_ptr() if dh is not None else None,
+                                                      g.data_ptr(), _stream()), "cox_blend_backward")
         return g, None, None, None
+
+
+_COX_DTYPES = {torch.float64: _lib.DT_F64, torch.float32: _lib.DT_F32, torch.int64: _lib.DT_I64, torch.int32: _lib.DT_I32, torch.uint8: _lib.DT_U8,
+               torch.bool: _lib.DT_U8}
+
+
+def _cox_operand(t: torch.Tensor):
+    """(contiguous tensor, MMNN_DT_* code): the kernel reads int64 / int32 / uint8 / bool / float32 / float64 directly (all exact in its
+    fp64 arithmetic); anything else (float16, int16, ...) is converted to float64 first."""
+    if t.dtype not in _COX_DTYPES:
+        t = t.to(torch.float64)
+    return (t if t.is_contiguous() else t.contiguous()), _COX_DTYPES[t.dtype]
 
 
 # ----------------------------------------------------------------------------------------------------------------------

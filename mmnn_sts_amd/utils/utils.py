@@ -10,7 +10,6 @@ import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _lib, ops
 
@@ -60,9 +59,10 @@ class MultiModalGradCAM(nn.Module):
     utils/utils.py:253-344 including its quirks: batch size 1 only (:334), channel-pooled gradients weight the activations
     IN PLACE and CUMULATIVELY across classes (:313-314), min-max normalisation, trilinear up-sampling to the input size.
 
-    The reference runs a full autograd backward per class and keeps only d out[0,cls] / d act.  Here the eval-mode forward
-    is the HIP backbone and that single gradient is evaluated in closed form (head -> feature_layer -> GAP -> ReLU mask ->
-    norm5 scale, restricted to the last `growth_rate` channels) -- no weight gradients are computed.
+    The reference runs a full autograd backward per class and keeps only d out[0,cls] / d act.  Here the eval-mode forward is the
+    HIP backbone and everything after it is ONE C-ABI call (`mmnn_gradcam`, csrc/gradcam.hip): that single gradient in closed form
+    (head -> feature_layer -> GAP -> ReLU mask -> norm5 scale, restricted to the last `growth_rate` channels; no weight gradients),
+    the pooled weighting, the channel mean, the min-max normalisation and the trilinear up-sampling.  torch allocates the outputs.
     """
 
     def __init__(self, model):
@@ -73,6 +73,7 @@ class MultiModalGradCAM(nn.Module):
         self.grads = None
 
     def forward(self, x):
+        import ctypes
         mm = self.model
         if getattr(mm, "blend", False):
             raise ValueError("MultiModalGradCAM expects blend=False (a (N, C) output), as main.py's inference path uses it")
@@ -87,36 +88,34 @@ class MultiModalGradCAM(nn.Module):
             ent = bb._plans[(tuple(image.shape), image.device.index)]
             L = _lib.lib()
             nb = len(bb.cfg["block_config"]) - 1
-            off = L.mmnn_densenet_ws_offset(ent["plan"], b"x", nb, 0)
             ctot, g = h.shape[1], bb.cfg["growth_rate"]
             sp = tuple(h.shape[2:])
             v = h[0, 0].numel()
-            xlast = ent["ws"][off:off + 4 * ctot * v].view(torch.float32).view(1, ctot, *sp)
-            act = xlast[:, ctot - g:].clone()                        # output of the last conv2 (dropout is off in eval)
+            # output of the last conv2 (dropout is off in eval) = the last `g` channels of the last block's concat buffer
+            act_in = ent["ws"].data_ptr() + L.mmnn_densenet_ws_offset(ent["plan"], b"x", nb, 0) + 4 * (ctot - g) * v
             fi = dn.features(h)
             fc = mm.clinical_model(x['clinical'])
             outputs = ops.FusionHeads.apply(fi, fc, mm.output_head.weight, mm.output_head.bias, mm.image_output_head.weight,
                                             mm.image_output_head.bias, mm.clinical_output_head.weight, mm.clinical_output_head.bias, False)
-            # d out[0, cls] / d act[c, v] = sum_f Wout[cls, f] * Wfeat[f, c'] / V * [h[c', v] > 0] * a5[c'],  c' = ctot - g + c
-            n5 = bb.norm5
-            a5 = (n5.weight / torch.sqrt(n5.running_var + n5.eps))[ctot - g:]
-            wfeat = dn.features.feature_layer.weight[:, ctot - g:]                     # (F, g)
-            wout = mm.output_head.weight[:, :wfeat.shape[0]]                           # (C, F) image half of the fused head
-            chan = (wout @ wfeat) * a5 / float(v)                                      # (C, g)
-            mask = (h[:, ctot - g:] > 0).to(torch.float32)                             # (1, g, d, h, w)
+            n5, wfeat, whead = bb.norm5, dn.features.feature_layer.weight, mm.output_head.weight
+            ncls = outputs.shape[1]
+            dev = h.device
             self.input_shape = image.shape
-            att_maps = []
-            for cls in range(outputs.shape[1]):
-                grads = mask * chan[cls].view(1, -1, 1, 1, 1)
-                self.grads = grads
-                pooled = grads.mean(dim=[0, 2, 3, 4])
-                act *= pooled.view(1, -1, 1, 1, 1)                                      # in place, cumulative (reference quirk)
-                heat = act.mean(dim=1).squeeze()
-                heat = heat - heat.min()
-                heat = heat / heat.max()
-                assert heat.ndim == 3, 'Batch dimension found in attention map - Must use batch size 1 when computing attention maps'
-                att_maps.append(F.interpolate(heat[None, None], self.input_shape[2:], mode='trilinear').squeeze())
-            self.features = act
+            D, H, W = (int(t) for t in image.shape[2:])
+            act = torch.empty((1, g) + sp, device=dev, dtype=torch.float32)
+            grads = torch.empty((1, g) + sp, device=dev, dtype=torch.float32)
+            heat = torch.empty((ncls,) + sp, device=dev, dtype=torch.float32)
+            maps = torch.empty((ncls, D, H, W), device=dev, dtype=torch.float32)
+            desc = _lib.GradcamDesc(ctot, g, sp[0], sp[1], sp[2], ncls, wfeat.shape[0], whead.shape[1], D, H, W, float(n5.eps))
+            for t in (h, wfeat, whead, n5.weight, n5.running_var):
+                if not (t.is_contiguous() and t.dtype == torch.float32):
+                    raise RuntimeError("MultiModalGradCAM expects contiguous float32 model tensors")
+            _lib.check(L.mmnn_gradcam(ctypes.byref(desc), h.data_ptr(), act_in, whead.data_ptr(), wfeat.data_ptr(), n5.weight.data_ptr(),
+                                      n5.running_var.data_ptr(), act.data_ptr(), grads.data_ptr(), heat.data_ptr(), maps.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "gradcam")
+            assert heat.ndim == 4, 'Batch dimension found in attention map - Must use batch size 1 when computing attention maps'
+            att_maps = list(maps.unbind(0))
+            self.features, self.grads, self.heat = act, grads, heat
         mm.train(was_training)
         return outputs, att_maps
 
@@ -128,17 +127,24 @@ def add_gradcam(model, output_dir='attention_maps', multimodal=False):
                               "only the multimodal Grad-CAM is part of this path")
 
 
+def remap_bhb_keys(entries):
+    """Key translation of the BHB-10K pretrained DenseNet121 checkpoint (utils/utils.py:368-384): drop the DataParallel prefix and
+    address a dense layer's leaves through its `layers` Sequential.  (The result still says `features.*` where this DenseNet says
+    `backbone.*` -- SURVEY Appendix A Q13 -- so with strict=False the convolutional weights match nothing, exactly as upstream.)"""
+    out = {}
+    for key, value in entries.items():
+        parts = key.replace('module.', '').split('.')
+        if parts[0] == 'features' and len(parts) > 1 and parts[1].startswith('dense'):
+            parts.insert(3, 'layers')
+        out['.'.join(parts)] = value
+    return out
+
+
 def loadWeights(model, path, device):
     """utils/utils.py:357-390 for local files: plain state_dict, or the BHB-10K pretrained DenseNet121 key remap."""
     checkpoint = torch.load(path, map_location=device)
     if isinstance(checkpoint, dict) and 'model' in checkpoint and path.endswith('DenseNet121_BHB-10K_yAwareContrastive.pth'):
-        remapped = {}
-        for key, value in checkpoint['model'].items():
-            parts = key.replace('module.', '').split('.')
-            if parts[0] == 'features' and parts[1].startswith('dense'):
-                parts.insert(3, 'layers')
-            remapped['.'.join(parts)] = value
-        model.load_state_dict(remapped, strict=False)
+        model.load_state_dict(remap_bhb_keys(checkpoint['model']), strict=False)
         logger.info('Loaded pretrained backbone')
     else:
         model.load_state_dict(checkpoint)

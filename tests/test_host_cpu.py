@@ -145,6 +145,28 @@ expect = sum(float(10 * r + k + 1) for r in range(world) for k in range(2))
 assert torch.allclose(net[0]._g, torch.full((70005,), expect)), (rank, net[0]._g[:3])
 assert torch.allclose(net[1].weight.grad, torch.full((3, 4), float(sum(r + 1 for r in range(world)))))
 assert torch.allclose(net[1].bias.grad, torch.full((3,), 2.0 * sum(r + 1 for r in range(world))))
+# the overlapped reducer: ranges reported from "inside the backward" are reduced at once, the rest in finish(); un-armed windows
+# reduce everything in finish().  Both must give exactly what allreduce_gradients gives.
+class HookedBackbone(FakeBackbone):
+    def set_grad_ready_hook(self, hook): self._hook = hook
+    def fake_backward(self, val):
+        self._g.fill_(val)
+        for b, e in ((40000, 70005), (10000, 40000), (0, 10000)):      # last block first, like the native backbone
+            if self._hook is not None: self._hook(self, b, e)
+net2 = torch.nn.Sequential(HookedBackbone(), torch.nn.Linear(4, 3))
+red = D.OverlappedGradientReducer(net2)
+for armed in (True, False, True):
+    if armed: red.arm()
+    net2[0].fake_backward(float(rank + 1))
+    net2[1].weight.grad = torch.full((3, 4), float(rank + 1)); net2[1].bias.grad = None
+    assert len(red._works) == (3 if armed else 0)
+    red.finish()
+    tot = float(sum(r + 1 for r in range(world)))
+    assert torch.equal(net2[0]._g, torch.full((70005,), tot)), (armed, net2[0]._g[:3])
+    assert torch.equal(net2[1].weight.grad, torch.full((3, 4), tot))
+    assert not red._works and not red._done and not red._armed
+red.detach()
+assert net2[0]._hook is None
 # max-over-ranks timing reduction used by bench.py
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -163,3 +185,43 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_kz_handoff_isa():
+    """the fence-free cross-workgroup K-split hand-off (csrc/fprop.hpp, MMNN_KZ_FENCED == 0) is only valid if the partial
+    tiles really leave with write-through stores and are read back with L1-bypassing loads.  Disassemble the gfx950 code objects of the
+    convolution translation units and check, for every kernel that takes a ticket (a returning agent-scope global_atomic_add), that
+    `global_store_dword ... sc1` precedes it and `global_load_dword ... sc1` follows it (16 per accumulator tile each)."""
+    import re
+    import shutil
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("ROCm LLVM tools not present")
+    objs = sorted(f for f in os.listdir(os.path.join(ROOT, "mmnn_sts_amd", "build")) if f.startswith("fprop_inst_") and f.endswith(".o"))
+    assert len(objs) >= 6, "build the library first (python -m mmnn_sts_amd.build)"
+    tmp = tempfile.mkdtemp()
+    checked = 0
+    try:
+        for o in objs:
+            shutil.copy(os.path.join(ROOT, "mmnn_sts_amd", "build", o), os.path.join(tmp, o))
+            r = subprocess.run([objdump, "--offloading", os.path.join(tmp, o)], capture_output=True, text=True)     # extracts the bundles next to the file
+            cos = [f for f in os.listdir(tmp) if f.startswith(o + ".") and "gfx950" in f]
+            assert r.returncode == 0 and len(cos) == 1, (r.stderr, os.listdir(tmp))
+            co = os.path.join(tmp, cos[0])
+            asm = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+            for name, body in re.findall(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", asm, flags=re.S | re.M):
+                if "fprop_kernel" not in name:
+                    continue
+                lines = body.splitlines()
+                tickets = [i for i, l in enumerate(lines) if "global_atomic_add " in l and "sc0" in l]     # returning 32-bit add = the ticket
+                if not tickets:
+                    continue
+                t = tickets[0]
+                st = sum(1 for l in lines[:t] if "global_store_dword " in l and " sc1" in l)
+                ld = sum(1 for l in lines[t:] if "global_load_dword " in l and " sc1" in l)
+                assert st >= 16 and ld >= 32, (o, name[:80], st, ld)
+                checked += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert checked >= 8, checked          # every small-extent tile (KZ_OK in fprop_dispatch.hpp) of the six instantiations

@@ -136,3 +136,65 @@ def test_synthetic_csv_round_trip(tmp_path):
     assert x.shape == (2, 32) and x.dtype == torch.float32 and ev.shape == (2, 2)
     with pytest.raises(ValueError):
         cli.ClinicalCsvDataset(path, preds + ["missing_column"])
+
+
+def test_bootstrap_c_indices():
+    """`--bootstrap` (main.py:767-768,857-887): 50 resamples with replacement of the evaluated patients, mean / std of the C-indices;
+    resamples without an admissible pair are skipped."""
+    rng = np.random.default_rng(11)
+    n = 24
+    du = rng.integers(1, 500, (n, 2)); ev = (rng.random((n, 2)) < 0.7).astype(int)
+    p = du / 500.0 + 0.05 * rng.standard_normal((n, 2))           # informative scores (lifelines' convention: a higher score = outlives)
+    means, stds, used = cli.bootstrap_c_indices(p, ev, du, iterations=50, seed=3)
+    assert used == 50 and len(means) == len(stds) == 2
+    full = cli.getCIndices(p, ev, du)
+    for m, s_, f in zip(means, stds, full):
+        assert 0.0 < s_ < 0.2 and abs(m - f) < 3 * s_ + 0.05 and m > 0.7
+    again = cli.bootstrap_c_indices(p, ev, du, iterations=50, seed=3)
+    assert again[0] == means and again[1] == stds                  # deterministic for a seed
+    # no admissible pair in any resample (nobody died): nothing usable, NaN summary, no exception
+    m0, s0, u0 = cli.bootstrap_c_indices(p, np.zeros_like(ev), du, iterations=5)
+    assert u0 == 0 and all(np.isnan(m0)) and all(np.isnan(s0))
+    # --bootstrap outside `--inference --survival` is rejected loudly
+    with pytest.raises(SystemExit):
+        cli.main(["--images", "--survival", "--bootstrap"])
+
+
+def test_load_weights_bhb_remap(tmp_path):
+    """utils/utils.py:357-390: a BHB-10K style checkpoint ({'model': {'module.features.denseblockB.denselayerL.<leaf>': ...}}) gets
+    'module.' stripped and 'layers' inserted after the dense layer; `strict=False`.  Quirk Q13: the remapped keys are
+    `features.*` while this DenseNet registers its backbone as `backbone.*`, so NONE of the convolutional weights land -- reproduced;
+    keys that do exist in the model (here: the classifier) are loaded."""
+    from mmnn_sts_amd.models.densenet import DenseNet
+    from mmnn_sts_amd.utils.utils import loadWeights, remap_bhb_keys
+    torch.manual_seed(0)
+    m = DenseNet(spatial_dims=3, in_channels=1, out_channels=2, feature_channels=12, block_config=(2, 2))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ck = {"model": {
+        "module.features.conv0.weight": torch.full((64, 1, 7, 7, 7), 7.0),
+        "module.features.denseblock1.denselayer1.norm1.weight": torch.full((64,), 3.0),
+        "module.features.denseblock1.denselayer2.conv2.weight": torch.full((32, 128, 3, 3, 3), 5.0),
+        "module.features.transition1.conv.weight": torch.full((64, 128, 1, 1, 1), 9.0),
+        "module.class_layers.out.weight": torch.full((2, 12), 0.25),
+    }}
+    remapped = remap_bhb_keys(ck["model"])
+    assert set(remapped) == {"features.conv0.weight", "features.denseblock1.denselayer1.layers.norm1.weight",
+                             "features.denseblock1.denselayer2.layers.conv2.weight", "features.transition1.conv.weight",
+                             "class_layers.out.weight"}
+    path = str(tmp_path / "DenseNet121_BHB-10K_yAwareContrastive.pth")
+    torch.save(ck, path)
+    loadWeights(m, path, "cpu")
+    after = m.state_dict()
+    assert torch.equal(after["class_layers.out.weight"], torch.full((2, 12), 0.25))               # the one key that exists lands
+    for k, v in before.items():
+        if k != "class_layers.out.weight":
+            assert torch.equal(after[k], v), k                                                     # Q13: the backbone is untouched
+    # a plain state_dict under any other file name loads strictly
+    plain = str(tmp_path / "model.pth")
+    sd = {k: v + 1 if v.is_floating_point() else v for k, v in before.items()}
+    torch.save(sd, plain)
+    loadWeights(m, plain, "cpu")
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    with pytest.raises(RuntimeError):
+        torch.save({"unexpected.key": torch.zeros(1)}, plain)
+        loadWeights(m, plain, "cpu")
