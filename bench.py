@@ -11,6 +11,10 @@ rank owns its own patients (weak scaling); value = volumes processed by ALL rank
 `--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (torch.distributed.run as a child process, before
 anything here touches the GPU) and relays rank 0's JSON line; every rank asserts that the process group really has N members.
 
+`--config unimodal` times BASELINE configs[1] (DenseNet121(in=1) + surv_criterion(CoxPH), 2 x 1 x 128^3) and `--config gradcam256`
+configs[4] (Grad-CAM inference of one 1 x 2 x 256^3 patient: eval forward + mmnn_gradcam, s/patient) the same way; they print a JSON line
+of their own metric (the headline line is the default `--config fusion`).
+
 Extra legs (rank 0, N = 1 only): `roofline` -- after the timed region, a few more (untimed) steps with every convolution launch
 bracketed by HIP events on its own launch stream and the backward serialised on one stream (un-overlapped durations); the
 kernel class with the largest total time is reported against the fp32 MFMA peak, the other classes beside it;
@@ -97,7 +101,39 @@ def class_flops(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32
     return sum(2.0 * n * v * mid * (c + growth * l) for l in range(blocks[block]))
 
 
-def kernel_roofline(L, plan, step, n, size, steps=4):
+HBM_ACHIEVABLE_TBS = 6.29         # measured copy rate (MI355X_MICROARCH.md HBM section; spec 8.0)
+HBM_SPEC_TBS = 8.0
+
+
+def class_bytes(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32, mid=128, init=64):
+    """ALGORITHMIC HBM bytes of ALL launches of one kernel class in one dense block during one step: every operand tensor read once,
+    every result written once (SURVEY 8(d) "fused minimum"; weight-gradient partial slabs are not algorithmic and not counted)."""
+    f = 4.0
+    if kind == 7:      # conv0: read x, write conv0 output (+ weights)
+        return f * (n * in_ch * size ** 3 + n * init * (size // 2) ** 3 + init * in_ch * 343)
+    if kind == 8:      # conv0 weight gradient: read x, dZ0 and conv0's output (BN backward on operand load), write dW
+        return f * (n * in_ch * size ** 3 + 2 * n * init * (size // 2) ** 3 + init * in_ch * 343)
+    v = (size // 4) ** 3
+    c = init
+    for b in range(block):
+        c = (c + blocks[b] * growth) // 2
+        v //= 8
+    nv = n * v
+    w2 = 27 * growth * mid
+    tot = 0.0
+    for l in range(blocks[block]):
+        cin = c + growth * l
+        w1 = mid * cin
+        if kind == 1:   tot += nv * (mid + growth) + w2                      # read T1, write the new channels
+        elif kind == 2: tot += nv * (2 * growth + 2 * mid) + w2              # read G and X slices, read T1 (mask), write dZ2
+        elif kind == 3: tot += nv * (2 * growth + mid) + w2                  # read G and X slices, read T1, write dW
+        elif kind == 4: tot += nv * (cin + mid) + w1                         # read the concat, write T1
+        elif kind == 5: tot += nv * (2 * mid + 3 * cin) + w1                 # read dZ2 and T1, read X (mask), read + write G
+        elif kind == 6: tot += nv * (2 * mid + cin) + w1                     # read dZ2 and T1, read X, write dW
+    return f * tot
+
+
+def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
     """Per-class device time of every convolution launch: events on the launch stream, backward on ONE stream so that the
     durations are not inflated by kernels overlapping on the side streams.  Runs `steps` extra steps after the timed region."""
     _lib_check = __import__("mmnn_sts_amd._lib", fromlist=["check"]).check
@@ -120,12 +156,22 @@ def kernel_roofline(L, plan, step, n, size, steps=4):
     for (kind, b), (ms, cnt) in rows.items():
         if cnt == 0:
             continue
-        flop = class_flops(kind, b, n, size) * steps
+        flop = class_flops(kind, b, n, size, in_ch=in_ch) * steps
+        byts = class_bytes(kind, b, n, size, in_ch=in_ch) * steps
         tf = flop / (ms * 1e-3) / 1e12
+        tbs = byts / (ms * 1e-3) / 1e12
         name = KCLASS[kind] + (f".b{b + 1}" if kind < 7 else "")
-        out.append({"class": name, "kernel": KDESC[kind] + (f", dense block {b + 1}" if kind < 7 else ""), "launches": int(cnt),
-                    "ms_per_step": ms / steps, "avg_us": ms / cnt * 1e3, "flop_per_launch": flop / cnt, "achieved": tf,
-                    "frac": tf / PEAK_FP32_TFLOPS})
+        # which roof bounds the class: the one its algorithmic work takes longer to cross
+        hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > flop / (PEAK_FP32_TFLOPS * 1e12)
+        row = {"class": name, "kernel": KDESC[kind] + (f", dense block {b + 1}" if kind < 7 else ""), "launches": int(cnt),
+               "ms_per_step": ms / steps, "avg_us": ms / cnt * 1e3, "flop_per_launch": flop / cnt, "bytes_per_launch": byts / cnt,
+               "bound": "hbm" if hbm_bound else "mfma", "mfma_tflops": tf, "mfma_frac": tf / PEAK_FP32_TFLOPS, "hbm_tbs": tbs,
+               "hbm_frac": tbs / HBM_ACHIEVABLE_TBS, "hbm_frac_of_spec": tbs / HBM_SPEC_TBS}
+        row["achieved"], row["peak"], row["unit"] = (tbs, HBM_ACHIEVABLE_TBS, "TB/s") if hbm_bound else (tf, PEAK_FP32_TFLOPS, "TFLOP/s")
+        row["frac"] = row["achieved"] / row["peak"]
+        if max(row["mfma_frac"], row["hbm_frac"]) < 0.15:
+            row["limiter"] = "latency"      # neither roof is near: a chain of memory round trips (the 8^3 / 4^3 layers)
+        out.append(row)
     out.sort(key=lambda r: -r["ms_per_step"])
     return out
 
@@ -167,7 +213,7 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(n=2, s=128, steps=3):
+def cpu_baseline(n=2, s=128, steps=5):
     """The oracle's plain-torch CPU path (kind "port"), same workload, bounded sample: 1 warm-up + `steps` timed steps."""
     from oracle import restatement as R
     from oracle import synth
@@ -205,16 +251,70 @@ def cpu_baseline(n=2, s=128, steps=3):
             "sample": f"{steps} timed steps (+1 warm-up) of the same micro-batch-2 128^3 step, {sec:.2f} s/step, torch {torch.__version__} CPU"}
 
 
+def measure_clock(L, dev):
+    """MHz sustained under a chip-wide fp32 MFMA load on THIS box (csrc/probe.hip): explains box-to-box differences of the fractions."""
+    mhz = ctypes.c_double()
+    scratch = torch.zeros(4, device=dev)
+    rc = L.mmnn_measure_mfma_clock(ctypes.byref(mhz), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return float(mhz.value) if rc == 0 else None
+
+
+def run_gradcam256(a, dev, L):
+    """BASELINE configs[4]: Grad-CAM attention maps of one 1 x 2 x S^3 patient (S = 256): eval-mode HIP forward + mmnn_gradcam."""
+    model = build_model(dev, blend=False).eval()
+    cam = model.add_gradcam("unused")
+    s = a.size
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = {"image": torch.randn((1, 2, s, s, s), device=dev, generator=g), "clinical": torch.randn((1, N_CLIN), device=dev, generator=g)}
+    for _ in range(max(2, a.warmup)):
+        cam(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        preds, maps = cam(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    # device time of the Grad-CAM arithmetic alone (everything after the model forward): events around the C-ABI call's kernels
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fwd_ms = []
+    for _ in range(3):
+        e0.record()
+        with torch.no_grad():
+            model.image_model.model.backbone(x["image"])
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_ms.append(e0.elapsed_time(e1))
+    fwd = sorted(fwd_ms)[1]
+    out_bytes = 4.0 * len(maps) * s ** 3
+    flops = 778.5e9 * (s / 256.0) ** 3                        # eval forward of one 2 x 256^3 volume (SURVEY 8(d))
+    assert torch.isfinite(preds).all() and all(torch.isfinite(m).all() for m in maps)
+    return {"metric": "Grad-CAM inference seconds/patient (1 x 2 x %d^3, configs[4])" % s, "value": dt, "unit": "s/patient",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4] --inference --images --preop --survival: eval forward of MultiModalModel(DenseNet121-3D(in=2), MLP(32)) "
+                                   "+ mmnn_gradcam (closed-form gradient, pooled weighting, min-max, trilinear up-sampling of 2 maps)",
+                       "volume": [2, s, s, s], "tabular": N_CLIN, "batch": 1},
+            "roofline": {"bound": "mfma", "kernel": "eval-mode backbone forward (all convolutions)", "achieved": flops / (fwd * 1e-3) / 1e12,
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": flops / (fwd * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+                         "backbone_forward_ms": fwd, "gradcam_tail_ms": dt * 1e3 - fwd,
+                         "upsample_bytes_written": out_bytes, "clock_mhz": measure_clock(L, dev)},
+            "reference_cpu_s_per_patient": "23-36 (BASELINE.md, reference on 8 vCPU)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--micro-batch", type=int, default=2)
+    ap.add_argument("--config", choices=("fusion", "unimodal", "gradcam256"), default="fusion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce after the whole backward instead of per dense block")
     a = ap.parse_args()
+    if a.size is None:
+        a.size = 256 if a.config == "gradcam256" else 128
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))
 
@@ -233,6 +333,12 @@ def main():
     local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    L = _lib.lib()
+    if a.config == "gradcam256":
+        if world != 1:
+            raise SystemExit("--config gradcam256 is a single-GPU inference benchmark")
+        print(json.dumps(run_gradcam256(a, dev, L)), flush=True)
+        return
     ranks_seen = 1
     if world > 1:
         assert torch.distributed.get_world_size() == a.gpus
@@ -240,7 +346,14 @@ def main():
         torch.distributed.all_reduce(seen)
         ranks_seen = int(seen.item())
         assert ranks_seen == a.gpus, f"{ranks_seen} ranks answered the all-reduce, expected {a.gpus}"
-    model = build_model(dev)
+    unimodal = a.config == "unimodal"
+    in_ch = 1 if unimodal else 2
+    if unimodal:
+        from mmnn_sts_amd.models.densenet import DenseNet121
+        torch.manual_seed(42)
+        model = DenseNet121(spatial_dims=3, in_channels=1, out_channels=2, feature_channels=12, dropout_prob=0.2).to(dev)
+    else:
+        model = build_model(dev)
     D.broadcast_parameters(model)
     model.train()
     opt = FusedSGD(model, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-4)
@@ -251,12 +364,22 @@ def main():
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total_steps)
     blender = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion)
     inputs, events, durations = synth_batch(dev, rank, a.micro_batch, a.size)
+    if unimodal:
+        inputs = inputs["image"][:, :1].contiguous()
+    # N > 1: the gradient all-reduce is issued per dense block from inside the backward (block 4 + norm5 first) and overlaps the
+    # kernels of the remaining blocks; `--no-overlap` reduces everything after the backward instead (same result bit for bit)
+    reducer = D.OverlappedGradientReducer(model) if (world > 1 and not a.no_overlap) else None
 
     def step():
         out = model(inputs)
-        loss, _ = blender.computeLoss(out, events, durations)
+        loss = surv_criterion(CoxPH, out, events, durations, dev) if unimodal else blender.computeLoss(out, events, durations)[0]
+        if reducer is not None:
+            reducer.arm()
         loss.backward()
-        D.allreduce_gradients(model)
+        if reducer is not None:
+            reducer.finish()
+        else:
+            D.allreduce_gradients(model)
         opt.step()
         sched.step()
         opt.zero_grad()
@@ -270,9 +393,8 @@ def main():
 
     for _ in range(init_steps + a.warmup):
         step()
-    bb = model.image_model.model.backbone
+    bb = model.backbone if unimodal else model.image_model.model.backbone
     plan = next(iter(bb._plans.values()))["plan"]
-    L = _lib.lib()
     timed_kernel = rank == 0 and world == 1 and not a.no_roofline
     barrier()
     t0 = time.perf_counter()
@@ -290,29 +412,46 @@ def main():
     if rank == 0:
         vols = a.steps * a.micro_batch * world
         value = vols / dt
+        gflop_vol = 245.9 if unimodal else GFLOP_PER_VOLUME      # in=1 / in=2
+        if unimodal:
+            metric = "training volumes/sec/GPU (128^3 T1, batch 2, configs[1]) on 1 MI355X"
+            unit = "volumes/s (1 volume = 1 patient = one T1 1x128^3 volume)"
+            workload = ("configs[1] --images --survival, modality t1: DenseNet121-3D(in=1) fwd + surv_criterion(CoxPH) + bwd + grad all-reduce + "
+                        "SGD-Nesterov/OneCycle step, dropout 0.2")
+        else:
+            metric = "training volumes/sec/GPU (128^3 T1+T2+preop, batch 2) at 1/2/4/8 MI355X"
+            unit = "volumes/s (whole job; 1 volume = 1 patient = stacked T1+T2 2x128^3 + 32 tabular)"
+            workload = ("configs[2] --images --preop --survival --blend: MultiModalModel(DenseNet121-3D(in=2), MLP(32), "
+                        "blend) fwd + GradientBlender Cox loss + bwd + grad all-reduce + SGD-Nesterov/OneCycle step, dropout 0.2")
         res = {
-            "metric": "training volumes/sec/GPU (128^3 T1+T2+preop, batch 2) at 1/2/4/8 MI355X",
-            "value": value, "unit": "volumes/s (whole job; 1 volume = 1 patient = stacked T1+T2 2x128^3 + 32 tabular)",
+            "metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup, "init_steps": init_steps, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "per_gpu": value / world,
-            "config": {"workload": "configs[2] --images --preop --survival --blend: MultiModalModel(DenseNet121-3D(in=2), MLP(32), "
-                                   "blend) fwd + GradientBlender Cox loss + bwd + grad all-reduce + SGD-Nesterov/OneCycle step, dropout 0.2",
-                       "micro_batch": a.micro_batch, "global_batch": a.micro_batch * world, "volume": [2, a.size, a.size, a.size],
-                       "tabular": N_CLIN, "parallelism": f"dp{world}"},
-            "step_fp32_frac_of_peak": value / world * GFLOP_PER_VOLUME / 1e3 / PEAK_FP32_TFLOPS if a.size == 128 else None,
+            "config": {"workload": workload, "micro_batch": a.micro_batch, "global_batch": a.micro_batch * world,
+                       "volume": [in_ch, a.size, a.size, a.size], "tabular": 0 if unimodal else N_CLIN, "parallelism": f"dp{world}",
+                       "allreduce": ("none" if world == 1 else ("per dense block, overlapped with the backward" if reducer is not None else "after the backward"))},
+            "step_fp32_frac_of_peak": value / world * gflop_vol / 1e3 / PEAK_FP32_TFLOPS if a.size == 128 else None,
         }
         if timed_kernel:
-            rows = kernel_roofline(L, plan, step, a.micro_batch, a.size)
+            rows = kernel_roofline(L, plan, step, a.micro_batch, a.size, in_ch=in_ch)
             top = rows[0]
-            res["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "class": top["class"], "achieved": top["achieved"],
-                               "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"], "traffic": measured_traffic(top["class"]),
+            clock = measure_clock(L, dev)
+            res["roofline"] = {"bound": top["bound"], "kernel": top["kernel"], "class": top["class"], "achieved": top["achieved"],
+                               "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": measured_traffic(top["class"]),
                                "launches_timed": top["launches"], "avg_us": top["avg_us"], "flop_per_launch": top["flop_per_launch"],
+                               "bytes_per_launch": top["bytes_per_launch"],
                                "ms_per_step": top["ms_per_step"], "step_frac": res["step_fp32_frac_of_peak"],
+                               "clock_mhz": clock, "nominal_clock_mhz": 2400.0,
+                               "frac_at_measured_clock": (top["frac"] * 2400.0 / clock) if (clock and top["bound"] == "mfma") else None,
                                "timing": "HIP events on the launch stream, 4 untimed steps after the timed region, backward on one stream",
+                               "bounds": "per class: 'mfma' (fraction of 157.3 TFLOP/s fp32) or 'hbm' (algorithmic bytes / time against 6.29 TB/s "
+                                         "measured copy rate, 8.0 spec), whichever roof its algorithmic work takes longer to cross; 'limiter: latency' "
+                                         "where neither fraction reaches 0.15",
                                "conv_ms_per_step": sum(r["ms_per_step"] for r in rows),
+                               "small_extent_ms_per_step": sum(r["ms_per_step"] for r in rows if r["class"].endswith((".b3", ".b4"))),
                                "classes": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"} for r in rows]}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not unimodal:
             res["cpu_baseline"] = cpu_baseline(a.micro_batch, a.size)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -262,6 +262,10 @@ typedef struct {
 int mmnn_gradcam(const mmnn_gradcam_desc* d, const float* h5, const float* act_in, const float* w_head, const float* w_feat,
                  const float* gamma5, const float* running_var5, float* act, float* grads, float* heat, float* maps, void* stream);
 
+/* ---- measurement aid (bench.py): MHz the chip sustains under a chip-wide v_mfma_f32_32x32x2_f32 load (one wave per SIMD, every CU), from
+ * the known cycle count of an MFMA loop and HIP events around it.  Synchronises the stream.  scratch: >= 1 float of device memory. */
+int mmnn_measure_mfma_clock(double* mhz, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,6 +216,9 @@ def train_survival(model, train_ds, val_ds, args, device, rank, world):
     opt = FusedSGD(model, lr=args.lr, momentum=args.momentum, nesterov=True, weight_decay=args.weight_decay)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=args.lr, steps_per_epoch=steps_per_epoch, epochs=args.epochs)
     blender = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion) if args.blend else None
+    # gradients are reduced once per accumulation window: the window's LAST backward is armed, so the all-reduce of a dense block's
+    # gradients starts inside that backward as soon as they are final and overlaps the kernels of the blocks still to come
+    reducer = D.OverlappedGradientReducer(model) if world > 1 else None
     cat_dim = 1 if args.blend else 0
     best = float("inf")
     for epoch in range(args.epochs):
@@ -225,10 +228,14 @@ def train_survival(model, train_ds, val_ds, args, device, rank, world):
             x, ev, du = to_device(x, device), ev.to(device), du.to(device)
             out = model(x)
             loss = blender.computeLoss(out, ev, du)[0] if args.blend else surv_criterion(CoxPH, out, ev, du, device)
+            boundary = is_step_boundary(i, len(loader), interval)
+            if boundary and reducer is not None:
+                reducer.arm()
             loss.backward()
             losses.append(loss.detach())
-            if is_step_boundary(i, len(loader), interval):
-                D.allreduce_gradients(model)
+            if boundary:
+                if reducer is not None:
+                    reducer.finish()
                 opt.step()
                 sched.step()
                 opt.zero_grad()

@@ -121,6 +121,7 @@ def lib():
         "mmnn_densenet_read_timer_class": [V, I, I, POINTER(ctypes.c_double), POINTER(c_int64)],
         "mmnn_densenet_set_option": [V, c_char_p, c_int64],
         "mmnn_densenet_set_batch_counters": [V, V, I],
+        "mmnn_measure_mfma_clock": [POINTER(ctypes.c_double), V, V],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

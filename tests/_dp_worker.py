@@ -59,7 +59,39 @@ def main():
     D.allreduce_gradients(mm)
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu().clone() for k, p in mm.named_parameters() if p.grad is not None}
-    torch.save({"loss": loss, "grads": grads, "world": torch.distributed.get_world_size()}, os.path.join(out, f"rank{rank}.pt"))
+    # The same window again with the all-reduce OVERLAPPED with the backward (per dense block, from inside backward()): bit-identical.
+    # Second pass: a two-micro-batch accumulation window where only the LAST backward is armed, against reducing after the window.
+    overlap_equal, ranges = True, []
+    mm.zero_grad(set_to_none=True)
+    bb = mm.image_model.model.backbone
+    bb.mark_grads_stale()
+    red = D.OverlappedGradientReducer(mm)
+    seen = red._on_range
+    def spy(b, begin, end):
+        ranges.append((begin, end)); seen(b, begin, end)
+    bb.set_grad_ready_hook(spy)
+    red.arm()
+    backward_micro_batch(mm, rank, dev)
+    early = len(red._works)
+    red.finish()
+    torch.cuda.synchronize()
+    for k, p in mm.named_parameters():
+        if p.grad is not None and not torch.equal(p.grad.detach().cpu(), grads[k]):
+            overlap_equal = False
+    window = {}
+    for mode in ("after", "overlap"):
+        mm.zero_grad(set_to_none=True)
+        bb.mark_grads_stale()
+        backward_micro_batch(mm, 2 * rank, dev)                   # accumulates locally: the reducer is not armed
+        if mode == "overlap":
+            red.arm()
+        backward_micro_batch(mm, 2 * rank + 1, dev)
+        red.finish()                                              # un-armed: reduces everything here
+        torch.cuda.synchronize()
+        window[mode] = {k: p.grad.detach().cpu().clone() for k, p in mm.named_parameters() if p.grad is not None}
+    window_equal = all(torch.equal(window["after"][k], window["overlap"][k]) for k in window["after"])
+    torch.save({"loss": loss, "grads": grads, "world": torch.distributed.get_world_size(), "overlap_equal": overlap_equal, "ranges": ranges,
+                "early_works": early, "window_equal": window_equal, "flat": bb.flat_grad.numel()}, os.path.join(out, f"rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

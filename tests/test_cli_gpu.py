@@ -70,3 +70,21 @@ def test_config2_fusion_blend_then_config4_gradcam(tmp_path):
     assert "All C-indexes" in log
     m = np.load(tmp_path / "attention_maps" / "patient0_att_map.npy")
     assert m.shape == (32, 32, 32) and np.isfinite(m).all() and m.min() >= 0.0 and m.max() <= 1.0 + 1e-6
+
+
+def test_bench_two_ranks_at_baseline_extent(tmp_path):
+    """BASELINE configs[3] rehearsal on ONE card: `bench.py --gpus 2 --size 128` starts its two ranks itself, the
+    ranks share the card over gloo (RCCL needs one device per rank), gradients are all-reduced per dense block from inside the backward.
+    The JSON line must report both ranks, a finite throughput and the overlapped schedule."""
+    import json
+    env = dict(os.environ, MMNN_DIST_BACKEND="gloo", MMNN_POISON_LDS="0", MMNN_POISON_WS="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "128", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == d["ranks_seen"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert d["config"]["allreduce"].startswith("per dense block") and d["scaling"] == "weak"
+    assert np.isfinite(d["value"]) and d["value"] > 0 and d["steps"] == 2

@@ -28,6 +28,13 @@ def test_two_ranks_allreduce_equals_sequential_accumulation(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert r0["world"] == r1["world"] == 2
+    # overlapped reduction (one all-reduce per dense block, issued from inside the backward): same bits as reducing afterwards, for a
+    # single backward and for a two-micro-batch accumulation window whose last backward is armed
+    for r in (r0, r1):
+        assert r["overlap_equal"] and r["window_equal"], (r["overlap_equal"], r["window_equal"])
+        assert r["early_works"] == 3 and len(r["ranges"]) == 3                       # TinyDensenet: three dense blocks
+        assert r["ranges"][0][1] == r["flat"] and r["ranges"][-1][0] == 0            # last block (+ norm5) first, stem with block 1
+        assert all(r["ranges"][i][0] == r["ranges"][i + 1][1] for i in range(2))     # the ranges tile the flat buffer, downwards
     assert r0["loss"] != r1["loss"]                       # the ranks really worked on different patients
     # one rank, the same two micro-batches accumulated (no zero_grad in between)
     dev = torch.device("cuda", 0)
