@@ -449,11 +449,26 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const WgradArgs a) {
 // each, far too few for 256 CUs, and independent of one another once the data-gradient chain has passed their layers.  The
 // argument table lives in device memory and is step-invariant; the per-step dropout seed arrives as a kernel argument.
 template <int PRO_X, int TD, int TH, int TW>
-__global__ void __launch_bounds__(512) wgrad3_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed) {
-  WgradArgs a = table[blockIdx.z];
-  if ((int)blockIdx.x >= a.nsplit || (int)blockIdx.y * 32 >= a.Cin) return;   // grid = the largest layer of the batch
+__global__ void __launch_bounds__(512) wgrad3_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed, const int nsplit,
+                                                             const int cgroups, const int ngroups) {
+  int z, split, cg;
+  if (ngroups > 0) {
+    // XCD-aware order (1-D grid): the `cgroups` blocks that share a (layer, split) pair -- they stage the SAME dOut tiles, only their
+    // 32 input channels differ -- are dealt to ONE XCD back to back (workgroups go round-robin over the 8 XCDs: blocks b and b + 8
+    // share one), so they run at the same time on neighbouring CUs and all but the first read dOut from that XCD's L2 instead of
+    // from HBM.  (r02: each channel group re-read dOut from memory: 3.05x the algorithmic bytes of this kernel.)
+    const int lin = blockIdx.x, x = lin & 7, j = lin >> 3;
+    const int G = x + 8 * (j / cgroups);
+    cg = j % cgroups;
+    if (G >= ngroups) return;
+    z = G / nsplit; split = G - z * nsplit;
+  } else {
+    z = blockIdx.z; split = blockIdx.x; cg = blockIdx.y;
+  }
+  WgradArgs a = table[z];
+  if (split >= a.nsplit || cg * 32 >= a.Cin) return;   // grid = the largest layer of the batch
   a.drop.seed = seed;
-  wgrad3_body<PRO_X, TD, TH, TW>(a, blockIdx.x, blockIdx.y);
+  wgrad3_body<PRO_X, TD, TH, TW>(a, split, cg);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -710,11 +725,30 @@ __global__ void __launch_bounds__(WC * 64) wgrad1_kernel(const WgradArgs a) {
 
 // several layers in one launch (blockIdx.z = layer; every layer of a batch has M <= 128): see wgrad3_batched_kernel
 template <int PRO_X, int WC>
-__global__ void __launch_bounds__(WC * 64) wgrad1_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed) {
-  WgradArgs a = table[blockIdx.z];
-  if ((int)blockIdx.x >= a.nsplit || (int)blockIdx.y * (32 * WC) >= a.Cin) return;
+__global__ void __launch_bounds__(WC * 64) wgrad1_batched_kernel(const WgradArgs* __restrict__ table, const uint64_t seed, const int count,
+                                                                 const int nsplit, const int members) {
+  int z, split, cg;
+  if (members > 0) {
+    // XCD-aware order (1-D grid, see wgrad3_batched_kernel): all (layer, channel group) blocks of ONE voxel split go to one XCD back to
+    // back.  They read the same voxel range: the channel groups of a layer share its 128-row dOut operand, and the layers share the
+    // concat buffer's channels -- one HBM read per XCD instead of one per block.
+    const int lin = blockIdx.x, x = lin & 7, j = lin >> 3;
+    split = x + 8 * (j / members);
+    if (split >= nsplit) return;
+    int m = j % members;
+    z = 0; cg = 0;
+    for (int i = 0; i < count; ++i) {                  // member m -> (layer, channel group): a few dozen layers at most
+      const int n = (table[i].Cin + 32 * WC - 1) / (32 * WC);
+      if (m < n) { z = i; cg = m; break; }
+      m -= n;
+    }
+  } else {
+    z = blockIdx.z; split = blockIdx.x; cg = blockIdx.y;
+  }
+  WgradArgs a = table[z];
+  if (split >= a.nsplit || cg * (32 * WC) >= a.Cin) return;
   a.drop.seed = seed;
-  wgrad1_body<PRO_X, WC>(a, blockIdx.x, blockIdx.y * (32 * WC), 0);
+  wgrad1_body<PRO_X, WC>(a, split, cg * (32 * WC), 0);
 }
 
 #endif  // __HIPCC__

@@ -1,4 +1,6 @@
 // 1x1x1 weight-gradient kernels: instantiations + launches (see wgrad_k3.hip).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "wgrad.hpp"
@@ -32,9 +34,21 @@ static int launch1_batched(const WgradArgs* host, const WgradArgs* dev, int coun
     MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     conf = true;
   }
-  int gx = 1, gy = 1;
-  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32 * WC)); }
-  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
+  int gx = 1, gy = 1, members = 0;
+  bool uniform = true;
+  for (int i = 0; i < count; ++i) {
+    gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32 * WC));
+    members += cdiv(host[i].Cin, 32 * WC);
+    uniform = uniform && host[i].nsplit == host[0].nsplit;
+  }
+  static const bool no_remap = [] { const char* e = getenv("MMNN_WG1_NO_XCD"); return e && e[0] == '1'; }();   // A/B knob
+  if (uniform && members > 1 && !no_remap) {
+    const long blocks = 8l * members * ((gx + 7) / 8);
+    MMNN_REQUIRE(blocks < (1l << 31), "wgrad batch: grid out of range");
+    MMNN_LAUNCH(kern, dim3((unsigned)blocks), dim3(C::NTHREADS), smem, stream, dev, seed, count, gx, members);
+  } else {
+    MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed, count, gx, 0);
+  }
   MMNN_HIP(hipGetLastError());
   return 0;
 }

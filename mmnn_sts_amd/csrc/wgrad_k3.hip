@@ -1,5 +1,7 @@
 // 3x3x3 weight-gradient kernels: instantiations + launches (its own translation unit: the kernels are heavily unrolled and this
 // file and wgrad_k1.hip are the two longest compiles of the build).  Host-side validation and split selection: wgrad.hip.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "wgrad.hpp"
@@ -34,8 +36,20 @@ static int launch3_batched(const WgradArgs* host, const WgradArgs* dev, int coun
     conf = true;
   }
   int gx = 1, gy = 1;
-  for (int i = 0; i < count; ++i) { gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32)); }
-  MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed);
+  bool uniform = true;
+  for (int i = 0; i < count; ++i) {
+    gx = std::max(gx, host[i].nsplit); gy = std::max(gy, cdiv(host[i].Cin, 32));
+    uniform = uniform && host[i].nsplit == host[0].nsplit && cdiv(host[i].Cin, 32) == cdiv(host[0].Cin, 32);
+  }
+  static const bool no_remap = [] { const char* e = getenv("MMNN_WG3_NO_XCD"); return e && e[0] == '1'; }();   // A/B knob
+  if (uniform && gy > 1 && !no_remap) {
+    const long ngroups = (long)count * gx;                       // (layer, split) pairs; each owns gy blocks on one XCD
+    const long blocks = 8l * gy * ((ngroups + 7) / 8);
+    MMNN_REQUIRE(blocks < (1l << 31), "wgrad batch: grid out of range");
+    MMNN_LAUNCH(kern, dim3((unsigned)blocks), dim3(C::NTHREADS), smem, stream, dev, seed, gx, gy, (int)ngroups);
+  } else {
+    MMNN_LAUNCH(kern, dim3(gx, gy, count), dim3(C::NTHREADS), smem, stream, dev, seed, gx, gy, 0);
+  }
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -73,6 +73,8 @@ def main():
     red.arm()
     backward_micro_batch(mm, rank, dev)
     early = len(red._works)
+    ranges = list(ranges)                                         # (the spy stays installed for the window passes below)
+    first_pass_ranges = list(ranges)
     red.finish()
     torch.cuda.synchronize()
     for k, p in mm.named_parameters():
@@ -90,7 +92,7 @@ def main():
         torch.cuda.synchronize()
         window[mode] = {k: p.grad.detach().cpu().clone() for k, p in mm.named_parameters() if p.grad is not None}
     window_equal = all(torch.equal(window["after"][k], window["overlap"][k]) for k in window["after"])
-    torch.save({"loss": loss, "grads": grads, "world": torch.distributed.get_world_size(), "overlap_equal": overlap_equal, "ranges": ranges,
+    torch.save({"loss": loss, "grads": grads, "world": torch.distributed.get_world_size(), "overlap_equal": overlap_equal, "ranges": first_pass_ranges,
                 "early_works": early, "window_equal": window_equal, "flat": bb.flat_grad.numel()}, os.path.join(out, f"rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
