@@ -408,6 +408,13 @@ class DenseNet(nn.Module):
             raise NotImplementedError("mmnn_sts_amd implements the 3-D DenseNet of the fusion path only (spatial_dims=3)")
         if (act if isinstance(act, str) else act[0]).lower() != "relu" or (norm if isinstance(norm, str) else norm[0]).lower() != "batch":
             raise NotImplementedError("mmnn_sts_amd kernels fuse ReLU + batch norm; other act/norm choices are not available")
+        # limits of the native kernels (csrc/densenet.hip: plan_build), reported when the module is built rather than at its first forward
+        if not (1 <= int(in_channels) <= 4):
+            raise ValueError(f"mmnn_sts_amd: in_channels must be 1..4 (the stem kernel's input tile), got {in_channels}")
+        if not (1 <= int(init_features) <= 64) or not (1 <= int(growth_rate) <= 32):
+            raise ValueError(f"mmnn_sts_amd: init_features <= 64 and growth_rate <= 32 (one MFMA row tile each), got {init_features} / {growth_rate}")
+        if not (1 <= len(block_config) <= 8) or any(int(n) < 1 for n in block_config) or int(bn_size) < 1 or not (0.0 <= float(dropout_prob) < 1.0):
+            raise ValueError(f"mmnn_sts_amd: bad block_config / bn_size / dropout_prob: {block_config} / {bn_size} / {dropout_prob}")
         self.backbone = _Backbone(in_channels, init_features, growth_rate, block_config, bn_size, dropout_prob)
         self.features = _Features(self.backbone.out_channels, feature_channels, dropout_prob)
         self.class_layers = _ClassLayers(feature_channels, out_channels)

@@ -225,3 +225,16 @@ def test_kz_handoff_isa():
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     assert checked >= 8, checked          # every small-extent tile (KZ_OK in fprop_dispatch.hpp) of the six instantiations
+
+
+def test_constructor_limits_are_reported_at_construction():
+    """VERDICT r02 weak 10: the native kernels serve a narrower constructor contract than the reference's DenseNet (INTEGRATION.md);
+    a configuration outside it must fail when the module is BUILT, with a ValueError, not at its first forward."""
+    from mmnn_sts_amd.models.densenet import DenseNet
+    ok = dict(spatial_dims=3, in_channels=2, out_channels=2, feature_channels=12, block_config=(2, 2))
+    DenseNet(**ok)
+    for bad in (dict(in_channels=5), dict(init_features=96), dict(growth_rate=48), dict(block_config=()), dict(dropout_prob=1.0), dict(bn_size=0)):
+        with pytest.raises(ValueError):
+            DenseNet(**{**ok, **bad})
+    with pytest.raises(NotImplementedError):
+        DenseNet(**{**ok, "spatial_dims": 2})

@@ -1,7 +1,13 @@
 """Stress of the cross-workgroup K-split hand-off of the small-extent convolutions (csrc/fprop.hpp): partial accumulator
-tiles travel between workgroups through HBM behind a ticket.  A missed write-through or a stale read would hand the last arriver an
-OLD partial tile -- with identical inputs that is the previous repetition's value and invisible, so every repetition scales the input
-differently and is compared with a plan that never splits (plan option "no_kz") on the same input.  The extents make the dispatcher pick
+tiles travel between workgroups through HBM behind a ticket.  A missed write-through or a stale read would hand the last arriver an OLD
+partial tile, i.e. the previous launch's value of that tile.  Three checks per repetition, on inputs that differ in PATTERN (a rescaled
+input is removed by the first batch norm and would make a stale tile equal to a fresh one):
+  * A, B, A: the second pass over input A must reproduce the first bit for bit although B's partial tiles lie in the scratch in between
+    (forward and backward: every kernel with a hand-off);
+  * the outputs agree with a plan that never splits (plan option "no_kz") to fp32 round-off -- only the association of the K sum differs;
+  * the gradients agree with that plan up to ReLU branch flips of near-zero pre-activations (percent-level per tensor
+    at these tiny extents), far below what a tile computed from another input would cause.
+The workspace starts as NaN (tests/_native.py), so a partial tile nobody wrote is caught as NaN.  The extents make the dispatcher pick
 kz = 2, 4 and 8 (fprop_dispatch.hpp: tiles * mtiles * kz <= 256)."""
 import ctypes
 
@@ -30,24 +36,41 @@ def test_kz_handoff_matches_unsplit(blocks, dhw, n):
     kz, ref = _pair(cfg, n, dhw)
     flat, run = kz.flatten(synth_sd(sch, "densenet."))
     run2 = run.clone()
-    x0 = torch.from_numpy(synth.uniform(f"kz/{blocks}", (n, 2) + dhw)).cuda()
     cot = torch.from_numpy(synth.uniform("kz/cot", kz.out_shape)).cuda()
-    worst = 0.0
-    for rep in range(12):
-        x = (x0 * (1.0 + 0.03 * rep)).contiguous()
-        out = kz.forward(flat, run, x, training=True)
-        g = kz.backward(flat, x, cot)
-        out_r = ref.forward(flat, run2, x, training=True)
-        g_r = ref.backward(flat, x, cot)
+    worst_o = worst_g = 0.0
+    for rep in range(6):
+        xa = torch.from_numpy(synth.uniform(f"kz/{blocks}/a{rep}", (n, 2) + dhw)).cuda()
+        xb = torch.from_numpy(synth.uniform(f"kz/{blocks}/b{rep}", (n, 2) + dhw)).cuda()
+        out1 = kz.forward(flat, run, xa, training=True)
+        g1 = kz.backward(flat, xa, cot)
+        kz.forward(flat, run, xb, training=True)
+        kz.backward(flat, xb, cot)
+        out3 = kz.forward(flat, run, xa, training=True)
+        g3 = kz.backward(flat, xa, cot)
+        out_r = ref.forward(flat, run2, xa, training=True)
+        g_r = ref.backward(flat, xa, cot)
         torch.cuda.synchronize()
-        assert torch.isfinite(out).all() and torch.isfinite(g).all()
-        # same arithmetic up to the association of the K sum (partial sums per slice instead of one chain): fp32 round-off only
-        eo = float((out - out_r).abs().max() / out_r.abs().max())
-        eg = float((g - g_r).norm() / g_r.norm())
-        worst = max(worst, eo, eg)
-        assert eo < 2e-4 and eg < 2e-4, (rep, eo, eg)
-        # and reproducible: the slices are summed in slice order whatever the arrival order
-        out2 = kz.forward(flat, run.clone(), x, training=True)
-        g2 = kz.backward(flat, x, cot)
-        assert torch.equal(out, out2) and torch.equal(g, g2), rep
-    print("worst relative deviation from the unsplit plan", worst)
+        assert torch.isfinite(out1).all() and torch.isfinite(g1).all()
+        assert torch.equal(out1, out3) and torch.equal(g1, g3), rep            # nothing of B's launch leaked into A's second pass
+        eo = float((out1 - out_r).abs().max() / out_r.abs().max())
+        eg = float((g1 - g_r).norm() / g_r.norm())
+        worst_o, worst_g = max(worst_o, eo), max(worst_g, eg)
+        assert eo < 2e-4 and eg < 3e-2, (rep, eo, eg)
+    print("worst relative deviation from the unsplit plan: output", worst_o, "gradient", worst_g)
+
+
+def test_kz_handoff_fenced_library_variant(tmp_path):
+    """The portable form of the hand-off (agent-scope release / acquire fences, csrc/fprop.hpp MMNN_KZ_FENCED=1) is what any target other
+    than gfx950 gets.  When the developer variant library has been built (`MMNN_KZ_FENCED=1 python -m mmnn_sts_amd.build`), the same
+    stress runs against it in a fresh process (MMNN_LIB_PATH); skipped otherwise."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mmnn_sts_amd", "libmmnn_sts_fenced.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmmnn_sts_fenced.so not built")
+    env = dict(os.environ, MMNN_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "matches_unsplit and blocks0"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
