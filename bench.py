@@ -77,14 +77,15 @@ def measured_traffic(key=None):
 
 
 KCLASS = {1: "conv2_fwd", 2: "conv2_dgrad", 3: "conv2_wgrad", 4: "conv1_fwd", 5: "conv1_dgrad", 6: "conv1_wgrad", 7: "stem_conv",
-          8: "stem_wgrad"}
+          8: "stem_wgrad", 9: "block_fwd"}
 KDESC = {1: "fprop_kernel<27,PRO_BNRELU,EPI_STORE_STATS> conv2 3x3x3 128->32 forward",
          2: "fprop_kernel<27,PRO_GRAD,EPI_MASK_STORE> conv2 3x3x3 data gradient 32->128",
          3: "wgrad3_kernel conv2 3x3x3 weight gradient",
          4: "fprop_kernel<1,PRO_BNRELU,EPI_STORE_STATS> conv1 1x1x1 C->128 forward",
          5: "fprop_kernel<1,PRO_GRAD,EPI_MASK_ACCUM> conv1 1x1x1 data gradient 128->C",
          6: "wgrad1_kernel conv1 1x1x1 weight gradient",
-         7: "stem_conv_kernel conv0 7x7x7 stride 2 forward", 8: "stem_wgrad_kernel conv0 weight gradient"}
+         7: "stem_conv_kernel conv0 7x7x7 stride 2 forward", 8: "stem_wgrad_kernel conv0 weight gradient",
+         9: "block_fwd_kernel: conv1 + conv2 forward of EVERY layer of the dense block, one persistent launch"}
 
 
 def class_flops(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32, mid=128, init=64):
@@ -96,9 +97,11 @@ def class_flops(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32
     for b in range(block):
         c = (c + blocks[b] * growth) // 2
         v //= 8
-    if kind in (1, 2, 3):
-        return blocks[block] * 2.0 * n * v * growth * mid * 27
-    return sum(2.0 * n * v * mid * (c + growth * l) for l in range(blocks[block]))
+    conv2 = blocks[block] * 2.0 * n * v * growth * mid * 27
+    conv1 = sum(2.0 * n * v * mid * (c + growth * l) for l in range(blocks[block]))
+    if kind == 9:
+        return conv1 + conv2
+    return conv2 if kind in (1, 2, 3) else conv1
 
 
 HBM_ACHIEVABLE_TBS = 6.29         # measured copy rate (MI355X_MICROARCH.md HBM section; spec 8.0)
@@ -124,7 +127,8 @@ def class_bytes(kind, block, n, size, in_ch=2, blocks=(6, 12, 24, 16), growth=32
     for l in range(blocks[block]):
         cin = c + growth * l
         w1 = mid * cin
-        if kind == 1:   tot += nv * (mid + growth) + w2                      # read T1, write the new channels
+        if kind == 9:   tot += nv * (cin + mid) + w1 + nv * (mid + growth) + w2   # both forward convolutions of the layer
+        elif kind == 1: tot += nv * (mid + growth) + w2                      # read T1, write the new channels
         elif kind == 2: tot += nv * (2 * growth + 2 * mid) + w2              # read G and X slices, read T1 (mask), write dZ2
         elif kind == 3: tot += nv * (2 * growth + mid) + w2                  # read G and X slices, read T1, write dW
         elif kind == 4: tot += nv * (cin + mid) + w1                         # read the concat, write T1
@@ -146,7 +150,7 @@ def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
         step()
         torch.cuda.synchronize()
         for kind in KCLASS:
-            for b in range(4 if kind < 7 else 1):
+            for b in range(1 if kind in (7, 8) else 4):
                 ms, cnt = ctypes.c_double(), ctypes.c_int64()
                 _lib_check(L.mmnn_densenet_read_timer_class(plan, kind, b, ctypes.byref(ms), ctypes.byref(cnt)), "read_timer")
                 rows[(kind, b)] = (ms.value, cnt.value)     # accumulated since set_timer
@@ -160,10 +164,10 @@ def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
         byts = class_bytes(kind, b, n, size, in_ch=in_ch) * steps
         tf = flop / (ms * 1e-3) / 1e12
         tbs = byts / (ms * 1e-3) / 1e12
-        name = KCLASS[kind] + (f".b{b + 1}" if kind < 7 else "")
+        name = KCLASS[kind] + ("" if kind in (7, 8) else f".b{b + 1}")
         # which roof bounds the class: the one its algorithmic work takes longer to cross
         hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > flop / (PEAK_FP32_TFLOPS * 1e12)
-        row = {"class": name, "kernel": KDESC[kind] + (f", dense block {b + 1}" if kind < 7 else ""), "launches": int(cnt),
+        row = {"class": name, "kernel": KDESC[kind] + ("" if kind in (7, 8) else f", dense block {b + 1}"), "launches": int(cnt),
                "ms_per_step": ms / steps, "avg_us": ms / cnt * 1e3, "flop_per_launch": flop / cnt, "bytes_per_launch": byts / cnt,
                "bound": "hbm" if hbm_bound else "mfma", "mfma_tflops": tf, "mfma_frac": tf / PEAK_FP32_TFLOPS, "hbm_tbs": tbs,
                "hbm_frac": tbs / HBM_ACHIEVABLE_TBS, "hbm_frac_of_spec": tbs / HBM_SPEC_TBS}

@@ -86,7 +86,9 @@ int mmnn_densenet_relu_mask(void* plan, const float* params, void* workspace, in
 int mmnn_densenet_set_timer(void* plan, int32_t kernel_class, int32_t block);
 int mmnn_densenet_read_timer(void* plan, double* total_ms, int64_t* launches);
 int mmnn_densenet_read_timer_class(void* plan, int32_t kernel_class, int32_t block, double* total_ms, int64_t* launches);
-/* plan options.  "no_kz" (0/1): never split the channel axis of a small-extent convolution over several workgroups (the tests' reference
+/* plan options.  "persistent_forward" (0/1, default 0; experiment): run the forward of a small-extent dense block (8^3 / 4^3 voxels) as ONE
+ * resident launch with grid barriers between the layers (csrc/blockfwd.hip) instead of two kernels per layer -- same results up to summation
+ * order; measured slower in round 3, kept for the record and under test.  "no_kz" (0/1): never split the channel axis of a small-extent convolution over several workgroups (the tests' reference
  * for the cross-workgroup hand-off).  "side_streams" (0, 1 or 2; default 0): run the weight-gradient kernels of the backward on that many side streams
  * beside the data-gradient chain instead of on the caller's stream -- same results.  "single_stream" (0/1): force 0 side streams
  * (un-overlapped kernel durations for profiling).  "params_version" (any non-zero

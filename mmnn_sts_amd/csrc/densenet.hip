@@ -18,6 +18,7 @@ static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // cross-block K-split scratch of the plan's workspace: <= 512 blocks x (up to 4) 32x32 partial tiles, + per-tile counters
 constexpr size_t KZ_PART_BYTES = (size_t)512 * 4 * 1024 * sizeof(float);
 constexpr unsigned KZ_CNT_ENTRIES = 4096;
+constexpr size_t BLK_SYNC_BYTES = 256;     // 2 words per dense block (MAX_BLOCKS = 8), zeroed together with the K-split counters
 
 namespace {
 struct Carver {
@@ -193,7 +194,8 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   for (int b = 0; b < nb; ++b) p.o_dz2[b] = cv.take((size_t)cfg.block_layers[b] * N * p.mid * p.Vb[b] * F);
   // cross-block K-split scratch: <= 256 blocks x one 32x32 (or 4 x 32x32) partial tile each, + per-tile counters
   p.o_kz_part = cv.take(KZ_PART_BYTES);
-  p.o_kz_cnt = cv.take(KZ_CNT_ENTRIES * sizeof(unsigned));
+  p.o_kz_cnt = cv.take(KZ_CNT_ENTRIES * sizeof(unsigned) + BLK_SYNC_BYTES);   // + the persistent block kernels' barrier words
+  p.o_blk_sync = p.o_kz_cnt + KZ_CNT_ENTRIES * sizeof(unsigned);
   // job tables
   int nlayers = 0;
   for (int b = 0; b < nb; ++b) nlayers += cfg.block_layers[b];
@@ -203,6 +205,15 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
   p.o_jobs_run = cv.take(sizeof(RunStatJob) * p.n_run_jobs);
   p.o_jobs_pack = cv.take(sizeof(PackJob) * p.n_pack_jobs);
   p.o_jobs_grad = cv.take(sizeof(GradJob) * p.n_grad_jobs);
+  p.o_jobs_blk = cv.take(sizeof(BlkLayer) * nlayers);
+  {
+    // r03 EXPERIMENT, off by default (plan option "persistent_forward" / MMNN_PERSISTENT=1): measured SLOWER than the per-layer
+    // kernels at 2 x 2 x 128^3 -- 31-43 us per layer against 26-28 (profiles/r03_ab_experiments.txt).
+    static const bool env_on = [] { const char* e = getenv("MMNN_PERSISTENT"); return e && e[0] == '1'; }();
+    p.persistent = env_on;
+    for (int b = 0; b < nb; ++b)
+      p.persist_b[b] = (p.cin_b[b] % 2 == 0) && block_fwd_supported(N, p.Db[b], p.Hb[b], p.Wb[b], p.ctot_b[b], p.mid, cfg.growth);
+  }
   p.n_layers = nlayers;
   p.o_wg_table = cv.take(sizeof(WgradArgs) * 2 * nlayers);     // [conv2 of every layer][conv1 of every layer], see plan_backward
   p.ws_bytes = cv.cur;
@@ -289,6 +300,23 @@ static bool build_tables(Plan& p, const float* params, float* run, char* ws) {
     j.src = s.sum; j.dst_off = db; gj[ig++] = j;    // dbeta
     p.max_grad = std::max(p.max_grad, (long)C);
   };
+  {   // per-layer table of the persistent block forward
+    BlkLayer* bl = reinterpret_cast<BlkLayer*>(hj + (p.o_jobs_blk - p.o_jobs_run));
+    int id = 0;
+    for (int b = 0; b < nb; ++b)
+      for (int l = 0; l < c.block_layers[b]; ++l, ++id) {
+        const LayerOff& lo = p.layers[b][l];
+        BlkLayer& e = bl[id];
+        memset(&e, 0, sizeof(e));
+        e.cin = lo.cin; e.layer_id = id;
+        e.w1 = fptr(ws, p.o_pk_c1[b][l]); e.w2 = fptr(ws, p.o_pk_c2f[b][l]);
+        e.g1 = params + lo.n1w; e.b1 = params + lo.n1b; e.g2 = params + lo.n2w; e.b2 = params + lo.n2b;
+        e.rm1 = run + lo.r1m; e.rv1 = run + lo.r1v; e.rm2 = run + lo.r2m; e.rv2 = run + lo.r2v;
+        e.t1 = fptr(ws, p.o_t1[b][l]);
+        const StatPtr st = statptr(ws, p.o_st_t1[b][l], p.mid, 0, p.nrep_b[b]);
+        e.st_t1_sum = st.sum; e.st_t1_sq = st.sq;
+      }
+  }
   const double cnt0 = (double)p.N * p.D0 * p.H0 * p.W0;
   run_job(p.o_st_conv0, c.init_features, 0, c.init_features, p.r_n0m, p.r_n0v, cnt0);
   pack_job(p.p_conv0, p.o_pk_conv0, (c.in_channels % 2 == 0) ? 3 : 4, c.init_features, c.in_channels, (long)7 * stem_krows(c.in_channels) * 64);
@@ -390,6 +418,7 @@ int plan_set_option(Plan& p, const char* name, long value) {
   if (s == "trace_slots") { p.trace_slots = (int)value; return 0; }
   if (s == "params_version") { p.params_version = value; return 0; }
   if (s == "no_kz") { p.no_kz = value != 0; return 0; }
+  if (s == "persistent_forward") { p.persistent = value != 0; return 0; }
   set_error("set_option: unknown option '%s'", s.c_str());
   return 1;
 }
@@ -428,7 +457,7 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   p.trace_seq = 0;
   lap(1);
   if (training) MMNN_HIP(hipMemsetAsync(ws + p.o_fstat, 0, p.fstat_bytes, stream));
-  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
+  MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned) + BLK_SYNC_BYTES, stream));
   lap(2);
   // The [k][m] weight panels only change when the parameters do.  A caller that can vouch for a version number (option
   // "params_version", non-zero) gets the repack skipped while it stays the same -- 31 of 32 forwards under the reference's
@@ -466,7 +495,24 @@ int plan_forward(Plan& p, const float* params, float* run, const float* x, char*
   for (int b = 0; b < nb; ++b) {
     const double cnt = (double)N * p.Vb[b];
     const long xns = (long)p.ctot_b[b] * p.Vb[b];
-    for (int l = 0; l < c.block_layers[b]; ++l, ++layer_id) {
+    const bool persistent = p.persist_b[b] && p.persistent;
+    if (persistent) {   // every layer of the block in ONE resident launch (blockfwd.hpp)
+      BlockFwdArgs q;
+      memset(&q, 0, sizeof(q));
+      q.N = N; q.D = p.Db[b]; q.H = p.Hb[b]; q.W = p.Wb[b];
+      q.cin0 = p.cin_b[b]; q.ctot = p.ctot_b[b]; q.mid = p.mid; q.growth = c.growth; q.nlayers = c.block_layers[b];
+      q.x = fptr(ws, p.o_x[b]); q.x_ns = xns;
+      const StatPtr sx = statptr(ws, p.o_st_x[b], p.ctot_b[b], 0, p.nrep_b[b]);
+      q.st_x_sum = sx.sum; q.st_x_sq = sx.sq; q.nrep = p.nrep_b[b];
+      q.layers = reinterpret_cast<const BlkLayer*>(ws + p.o_jobs_blk) + layer_id;
+      q.sync = reinterpret_cast<unsigned*>(ws + p.o_blk_sync) + 2 * b;
+      q.inv_count = 1.0 / cnt; q.eps = c.eps; q.training = training;
+      q.seed = seed; q.drop_p = training ? c.dropout_p : 0.f;
+      { ScopedTimer t(p, T_BLOCK_FWD, b, stream); rc = launch_block_fwd(q, stream); }
+      if (rc) return rc;
+      layer_id += c.block_layers[b];
+    }
+    for (int l = 0; l < c.block_layers[b] && !persistent; ++l, ++layer_id) {
       const LayerOff& lo = p.layers[b][l];
       FpropArgs a;
       memset(&a, 0, sizeof(a));
@@ -614,7 +660,7 @@ int plan_backward_range(Plan& p, const float* params, const float* x, char* ws, 
   const bool first_call = hi == nb - 1;
   if (first_call) {
     MMNN_HIP(hipMemsetAsync(ws + p.o_bstat, 0, p.bstat_bytes, stream));
-    MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned), stream));
+    MMNN_HIP(hipMemsetAsync(ws + p.o_kz_cnt, 0, KZ_CNT_ENTRIES * sizeof(unsigned) + BLK_SYNC_BYTES, stream));
   }
   p.bwd_next = lo - 1;
   // Two streams: the data-gradient chain (conv2 dgrad -> conv1 dgrad -> next layer) is the critical path; the weight-gradient
@@ -974,6 +1020,7 @@ long plan_ws_offset(const Plan& p, const char* name, int i, int j) {
   if (s == "pk_c2f" && okl(i, j)) return (long)p.o_pk_c2f[i][j];
   if (s == "pk_c2b" && okl(i, j)) return (long)p.o_pk_c2b[i][j];
   if (s == "pk_conv0") return (long)p.o_pk_conv0;
+  if (s == "blk_sync") return (long)p.o_blk_sync;
   if (s == "#pack_launches") return p.pack_launches;      // counter, not an offset (tests)
   return -1;
 }

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "blockfwd.hpp"
 #include "elementwise.hpp"
 
 namespace mmnn {
@@ -61,7 +62,10 @@ struct Plan {
   std::vector<size_t> o_sl_tr; std::vector<int> ns_tr;
   // device job tables (inside the workspace) + pinned host staging
   size_t o_kz_part, o_kz_cnt;                       // cross-block K-split scratch (fprop.hpp)
-  size_t o_jobs_run, o_jobs_pack, o_jobs_grad;
+  size_t o_jobs_run, o_jobs_pack, o_jobs_grad, o_jobs_blk;   // o_jobs_blk: BlkLayer table of the persistent block forward
+  size_t o_blk_sync = 0;                            // 2 words per dense block: arrival counter, error flag (zeroed with kz_cnt)
+  bool persist_b[MAX_BLOCKS] = {false};             // block CAN run as ONE persistent forward launch (blockfwd.hpp)
+  bool persistent = false;                          // option "persistent_forward" (experiment, default off): use the persistent launch where supported
   int n_layers = 0;
   int wg_group[MAX_BLOCKS] = {0};                  // dense layers per weight-gradient launch, by block
   size_t o_wg_table = 0;                            // device tables of the weight-gradient arguments (batched launches)
@@ -92,7 +96,7 @@ struct Plan {
 };
 
 enum TimerKind { T_NONE = 0, T_CONV2_FWD = 1, T_CONV2_DGRAD = 2, T_CONV2_WGRAD = 3, T_CONV1_FWD = 4, T_CONV1_DGRAD = 5,
-                 T_CONV1_WGRAD = 6, T_STEM_CONV = 7, T_STEM_WGRAD = 8, T_COUNT = 9 };
+                 T_CONV1_WGRAD = 6, T_STEM_CONV = 7, T_STEM_WGRAD = 8, T_BLOCK_FWD = 9, T_COUNT = 10 };
 int plan_set_timer(Plan& p, int kind, int block);                              // kind -1: every class
 int plan_read_timer(Plan& p, int kind, int block, double* total_ms, long* count);   // kind 0 / block < 0: all of them together
 int plan_set_option(Plan& p, const char* name, long value);

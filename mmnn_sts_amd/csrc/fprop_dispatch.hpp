@@ -77,11 +77,11 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
     // hides the staging latency better than loader waves or KC = 4 do here (194 -> 173 us at block 1).
     // Tried and measured slower for the data gradient at 32^3 (r02): 64-voxel tiles / 4 blocks per CU (180 us, register
     // allocation still caps the CU at 3 waves per SIMD), 8 waves with an in-block K-split and KC = 4 (231 us), loader waves (213 us).
-    // r03 experiment (MMNN_DGRAD_TILE=1): ONE 8-wave block of 128 rows x 256 voxels (2 x 4 x 32) per CU instead of two 4-wave blocks of
-    // 128 x 128: the 442 KB of weights are staged once per 256 voxels instead of once per 128, the halo shrinks from 4.8x to 3.2x of
-    // the tile, and a thread stages 4 + 1 items per chunk instead of 7 + 4.  What it gives up: the two independent blocks of a CU
-    // interleave their staging and MFMA phases by themselves; the two waves of a SIMD of ONE block meet every barrier together.
-    static const int big = [] { const char* e = getenv("MMNN_DGRAD_TILE"); return e ? atoi(e) : 0; }();
+    // r03: ONE 8-wave block of 128 rows x 256 voxels (2 x 4 x 32) per CU instead of two 4-wave blocks of 128 x 128: the 442 KB of weights
+    // are staged once per 256 voxels instead of once per 128, the halo shrinks from 4.8x to 3.2x of the tile, a thread stages 4 + 1 items
+    // per chunk instead of 7 + 4, and the kernel needs 163 registers instead of 228 + 64 accumulation registers.  Measured on the conv2
+    // data gradient of block 1 (A/B in one process, profiles/r03_ab_experiments.txt): 141.6 -> 137.7 us.  MMNN_DGRAD_TILE=0: the r02 tile.
+    static const int big = [] { const char* e = getenv("MMNN_DGRAD_TILE"); return e ? atoi(e) : 1; }();
     if (big == 1) return launch_cfg<27, PRO, EPI, 2, 4, 1, 2, 2, 2, 2, 4, 32>(a, s);
     return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
   }

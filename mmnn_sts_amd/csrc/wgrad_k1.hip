@@ -41,8 +41,10 @@ static int launch1_batched(const WgradArgs* host, const WgradArgs* dev, int coun
     members += cdiv(host[i].Cin, 32 * WC);
     uniform = uniform && host[i].nsplit == host[0].nsplit;
   }
-  static const bool no_remap = [] { const char* e = getenv("MMNN_WG1_NO_XCD"); return e && e[0] == '1'; }();   // A/B knob
-  if (uniform && members > 1 && !no_remap) {
+  // r03 A/B (profiles/r03_ab_experiments.txt): the XCD-aware order measured 2-3 % SLOWER here (block 1: 285 vs 278 us) -- unlike the 3x3x3
+  // kernel the blocks of one split do not stage the same tiles in lockstep (their channel counts differ), so it stays off: MMNN_WG1_XCD=1
+  static const bool remap = [] { const char* e = getenv("MMNN_WG1_XCD"); return e && e[0] == '1'; }();
+  if (uniform && members > 1 && remap) {
     const long blocks = 8l * members * ((gx + 7) / 8);
     MMNN_REQUIRE(blocks < (1l << 31), "wgrad batch: grid out of range");
     MMNN_LAUNCH(kern, dim3((unsigned)blocks), dim3(C::NTHREADS), smem, stream, dev, seed, count, gx, members);

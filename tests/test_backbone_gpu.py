@@ -206,3 +206,86 @@ def test_backbone_side_streams_are_equivalent(side):
     _lib.check(_lib.lib().mmnn_densenet_set_option(nb.plan, b"side_streams", 0), "set_option")
     nb.forward(flat, run.clone(), x, True, seed=9)
     assert torch.equal(nb.backward(flat, x, cot, seed=9), ref)
+
+
+# Persistent block forward (csrc/blockfwd.hip; opt-in experiment, plan option "persistent_forward"): the 8^3 / 4^3 dense blocks run as ONE
+# resident launch with grid barriers between the layers' phases.  Cases: (blocks, input extent, N) -> extents of the persistent blocks
+#   (2,2,3,2) 128^3 N=1   block 3: 8^3 (64 workgroups, chip-wide barrier), block 4: 4^3 (8 workgroups on one XCD)
+#   (2,2,3,2) 128^3 N=3   192 / 24 workgroups (tiles of three samples)
+#   (2,2,2) 64x128x256 N=2  block 3: 4x8x16 (W = 16: one-row tiles), block 2 (W = 32) stays on the per-layer kernels
+PERSISTENT = [((2, 2, 3, 2), (128, 128, 128), 1), ((2, 2, 3, 2), (128, 128, 128), 3), ((2, 2, 2), (64, 128, 256), 2)]
+
+
+@pytest.mark.parametrize("blocks,dhw,n", PERSISTENT)
+def test_persistent_block_forward_matches_layer_kernels(blocks, dhw, n):
+    """Same arithmetic, other summation order (K split over the waves of one workgroup instead of over workgroups): every tensor the
+    block produces -- bottleneck tensors, concat buffer, output, running statistics -- agrees with the per-layer kernels to fp32
+    round-off, in training and in eval mode; the gradients of a backward that consumes the persistent forward's tensors agree up to ReLU
+    branch flips of near-zero pre-activations; a repeated launch reproduces itself bit for bit; the barrier error flag stays clear."""
+    from mmnn_sts_amd import _lib
+    from tests._native import NativeBackbone
+    cfg = R.DenseNetCfg(in_channels=2, block_config=blocks)
+    sch = R.densenet_schema(cfg)
+    a, b = NativeBackbone(cfg, n, *dhw), NativeBackbone(cfg, n, *dhw)
+    _lib.check(a.L.mmnn_densenet_set_option(a.plan, b"persistent_forward", 1), "set_option")      # opt-in experiment (default: per-layer kernels)
+    flat, run_a = a.flatten(synth_sd(sch, "densenet."))
+    run_b = run_a.clone()
+    x = torch.from_numpy(synth.uniform(f"pb/{blocks}/{n}", (n, 2) + dhw)).cuda()
+    cot = torch.from_numpy(synth.uniform("pb/cot", a.out_shape)).cuda()
+    for training in (True, False):
+        oa = a.forward(flat, run_a, x, training=training, seed=11)
+        ob = b.forward(flat, run_b, x, training=training, seed=11)
+        torch.cuda.synchronize()
+        assert torch.isfinite(oa).all()
+        assert rel_err(oa.cpu().numpy(), ob.cpu().numpy()) < 2e-5, training
+        dims = [(s - 1) // 2 + 1 for s in dhw]
+        dims = [(s - 1) // 2 + 1 for s in dims]
+        c = cfg.init_features
+        for blk, nl in enumerate(blocks):
+            ctot = c + nl * cfg.growth_rate
+            xa = a.region("x", (n, ctot, *dims), blk)
+            xb = b.region("x", (n, ctot, *dims), blk)
+            assert rel_err(xa.cpu().numpy(), xb.cpu().numpy()) < 2e-5, (training, blk)
+            for l in range(nl):
+                ta = a.region("t1", (n, cfg.bn_size * cfg.growth_rate, *dims), blk, l)
+                tb = b.region("t1", (n, cfg.bn_size * cfg.growth_rate, *dims), blk, l)
+                assert rel_err(ta.cpu().numpy(), tb.cpu().numpy()) < 2e-5, (training, blk, l)
+            c, dims = ctot // 2, [s // 2 for s in dims]
+        if training:
+            assert rel_err(run_a.cpu().numpy(), run_b.cpu().numpy()) < 1e-5
+            ga = a.backward(flat, x, cot, seed=11)
+            gb = b.backward(flat, x, cot, seed=11)
+            oa2 = a.forward(flat, run_a.clone(), x, training=True, seed=11)
+            ga2 = a.backward(flat, x, cot, seed=11)
+            torch.cuda.synchronize()
+            assert float((ga - gb).norm() / gb.norm()) < 3e-2
+            assert torch.equal(oa, oa2) and torch.equal(ga, ga2)
+    off = a.L.mmnn_densenet_ws_offset(a.plan, b"blk_sync", 0, 0)
+    assert off >= 0
+    words = a.ws[off:off + 64].view(torch.int32).cpu()
+    assert int(words[1::2].abs().sum()) == 0, words            # no barrier gave up
+    assert int(words[0::2].sum()) > 0                           # ... and the persistent kernels really ran
+
+
+def test_persistent_block_forward_dropout_streams_match():
+    """Channel dropout inside the persistent launch uses the same counter-based stream (seed, layer, sample, channel) as the per-layer
+    kernels: with p = 0.3 both plans must drop exactly the same channels."""
+    from mmnn_sts_amd import _lib
+    from tests._native import NativeBackbone
+    cfg = R.DenseNetCfg(in_channels=2, block_config=(2, 2, 3, 2))
+    sch = R.densenet_schema(cfg)
+    a, b = NativeBackbone(cfg, 2, 128, 128, 128, dropout=0.3), NativeBackbone(cfg, 2, 128, 128, 128, dropout=0.3)
+    _lib.check(a.L.mmnn_densenet_set_option(a.plan, b"persistent_forward", 1), "set_option")
+    flat, run = a.flatten(synth_sd(sch, "densenet."))
+    x = torch.from_numpy(synth.uniform("pb/drop", (2, 2, 128, 128, 128))).cuda()
+    oa = a.forward(flat, run.clone(), x, training=True, seed=77)
+    ob = b.forward(flat, run.clone(), x, training=True, seed=77)
+    torch.cuda.synchronize()
+    c = cfg.init_features
+    for nl in cfg.block_config[:-1]:
+        c = (c + nl * cfg.growth_rate) // 2
+    ctot = c + cfg.block_config[-1] * cfg.growth_rate          # channels of the last block's concat buffer (4^3 voxels at 128^3)
+    xa, xb = a.region("x", (2, ctot, 4, 4, 4), 3), b.region("x", (2, ctot, 4, 4, 4), 3)
+    za, zb = (xa.abs().sum(dim=(2, 3, 4)) == 0), (xb.abs().sum(dim=(2, 3, 4)) == 0)
+    assert torch.equal(za, zb) and 0 < int(za.sum()) < za.numel() // 2
+    assert rel_err(oa.cpu().numpy(), ob.cpu().numpy()) < 2e-5

@@ -18,11 +18,19 @@ if has tests; then
 fi
 if has bench; then
   python bench.py > "$O/bench_line.json" 2> "$O/bench_line.err"
-  cat "$O/bench_line.json"
+  python tools/show_bench.py "$O/bench_line.json"
+  python bench.py --config unimodal --no-cpu-baseline > "$O/bench_unimodal.json" 2> "$O/bench_unimodal.err"
+  python tools/show_bench.py "$O/bench_unimodal.json" | head -3
+  python bench.py --config gradcam256 --steps 10 --warmup 3 > "$O/bench_gradcam256.json" 2> "$O/bench_gradcam256.err"
+  cat "$O/bench_gradcam256.json"
+  ./tools/microbench/grid_barrier.bin > "$O/grid_barrier.txt" 2>&1 || true
+  ./tools/microbench/mfma_valu_overlap.bin > "$O/mfma_valu_overlap.txt" 2>&1 || true
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then
   rocprofv3 --kernel-trace --stats -d "$O/prof_ss" -o ss --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/prof_ss.err"
+  rocprofv3 --kernel-trace --stats -d "$O/prof_gc" -o gc --output-format csv -- python3 "$R/bench.py" --config gradcam256 --steps 5 --warmup 2 > "$O/bench_gradcam256_under_rocprof.json" 2> "$O/prof_gc.err"
+  find "$O/prof_gc" -name "*kernel_trace.csv" -delete
   find "$O/prof_ss" -name "*kernel_trace.csv" -delete
 fi
 pmc_pass() { local name="$1"; shift
