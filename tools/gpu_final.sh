@@ -20,7 +20,7 @@ if has bench; then
   python bench.py > "$O/bench_line.json" 2> "$O/bench_line.err"
   python tools/show_bench.py "$O/bench_line.json"
   python bench.py --config unimodal --no-cpu-baseline > "$O/bench_unimodal.json" 2> "$O/bench_unimodal.err"
-  python tools/show_bench.py "$O/bench_unimodal.json" | head -3
+  python tools/show_bench.py "$O/bench_unimodal.json" > "$O/bench_unimodal.txt"
   python bench.py --config gradcam256 --steps 10 --warmup 3 > "$O/bench_gradcam256.json" 2> "$O/bench_gradcam256.err"
   cat "$O/bench_gradcam256.json"
   ./tools/microbench/grid_barrier.bin > "$O/grid_barrier.txt" 2>&1 || true
