@@ -445,3 +445,30 @@ def test_eval_mode_backward_raises_and_n1_training_rejected():
     mlp = MLP(N_CLIN, 2, 12).to(DEV).train()
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         mlp(torch.randn(1, N_CLIN, device=DEV))
+
+
+@pytest.mark.parametrize("dhw", [(96, 64, 70), (64, 96, 128)])
+def test_gradcam_ragged_extents_vs_oracle(dhw):
+    """`mmnn_gradcam` off the cubic golden extents: a non-cubic captured layer (6x4x4 / 4x6x8), an output width that is not a multiple of 4
+    (70: the up-sampling kernel's scalar store path) and one that is (128: 16-byte stores), against the fp64 oracle's autograd Grad-CAM
+    (utils/utils.py:293-344 restated: per-class backward, in-place cumulative weighting, min-max, F.interpolate trilinear)."""
+    from mmnn_sts_amd.models.densenet import DenseNet
+    from mmnn_sts_amd.models.multimodal import MultiModalModel
+    cfg = R.DenseNetCfg(in_channels=2, block_config=(2, 2, 2))
+    sch = R.multimodal_schema(cfg, N_CLIN, 2, 12)
+    img = DenseNet(spatial_dims=3, in_channels=2, out_channels=2, feature_channels=12, block_config=(2, 2, 2), dropout_prob=0.2)
+    mm = MultiModalModel(img, [f"p{i}" for i in range(N_CLIN)], 2, 12, blend=False)
+    _load(mm, sch, "fusion.")
+    mm = mm.to(DEV).eval()
+    image = torch.from_numpy(synth.uniform(f"gc/{dhw}", (1, 2) + dhw))
+    clinical = clin_in(1)
+    cam = mm.add_gradcam("unused")
+    preds, maps = cam({"image": image.to(DEV), "clinical": clinical.to(DEV)})
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in synth_sd(sch, "fusion.").items()}
+    ref_out, ref_maps, ref_small = R.multimodal_gradcam(sd64, image.double(), clinical.double(), cfg)
+    assert rel_err(preds.cpu().numpy(), ref_out.numpy()) < 1e-4
+    assert len(maps) == 2 and tuple(maps[0].shape) == dhw and tuple(cam.heat.shape) == (2,) + tuple(ref_small[0].shape)
+    for i in range(2):
+        np.testing.assert_allclose(cam.heat[i].cpu().numpy(), ref_small[i].numpy(), rtol=2e-3, atol=2e-4)       # normalised low-resolution map
+        np.testing.assert_allclose(maps[i].cpu().numpy(), ref_maps[i].numpy(), rtol=2e-3, atol=3e-4)            # every up-sampled voxel
+        assert float(maps[i].min()) >= -1e-6 and float(maps[i].max()) <= 1.0 + 1e-6
