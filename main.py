@@ -441,9 +441,10 @@ def main(argv=None):
     model = parser.getModel(a)
     if a.multimodal:
         model.blend = a.blend
-    rank, world, local = D.init_from_env("nccl")
+    rank, world, local = D.init_from_env(os.environ.get("MMNN_DIST_BACKEND", "nccl"))    # "nccl" = RCCL; gloo only for rehearsals on one card
     if not torch.cuda.is_available():
         raise SystemExit("mmnn_sts_amd runs on the MI355X only (no CPU path)")
+    local = local % max(1, torch.cuda.device_count())            # (gloo rehearsals: several ranks share a card)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if a.weights:

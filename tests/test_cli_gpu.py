@@ -88,3 +88,40 @@ def test_bench_two_ranks_at_baseline_extent(tmp_path):
     assert d["n_gpus"] == d["ranks_seen"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
     assert d["config"]["allreduce"].startswith("per dense block") and d["scaling"] == "weak"
     assert np.isfinite(d["value"]) and d["value"] > 0 and d["steps"] == 2
+
+
+def _run_ranks(args, out, world=2):
+    """main.py under torch.distributed.run, `world` ranks sharing the one card over gloo (on an 8-GPU node the same command runs over RCCL)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MMNN_DIST_BACKEND="gloo", MMNN_POISON_LDS="0", MMNN_POISON_WS="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "main.py"), "--output_path", str(out), *args], cwd=str(out), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout + r.stderr
+
+
+def test_two_rank_survival_blend_and_classification(tmp_path):
+    """The CLI's data-parallel paths on two ranks: survival + GradientBlender (accumulation windows whose last backward arms the overlapped
+    reducer, blender update on gathered predictions, rank 0 saves) and classification (broadcast, all-reduce before every
+    optimizer step, checkpoints written by rank 0 only)."""
+    from mmnn_sts_amd.models.densenet import TinyDensenet
+    from mmnn_sts_amd.models.mlp import MLP
+    from mmnn_sts_amd.models.multimodal import MultiModalModel
+    cfg = _tiny_config(tmp_path)
+    a = tmp_path / "surv"; a.mkdir()
+    log = _run_ranks(["--images", "--preop", "--survival", "--blend", "--blend_update_interval", "1", "--epochs", "1", "--synthetic_patients", "6",
+                      "--synthetic_size", "32", "--config", cfg], a)
+    assert "Completed updating gradient blender weights" in log and log.count("saved new best metric model") == 1      # rank 0 only
+    img = TinyDensenet(spatial_dims=3, in_channels=2, out_channels=2, feature_channels=12, dropout_prob=0.2)
+    MultiModalModel(img, [f"p{i}" for i in range(32)], 2, 12, blend=True).load_state_dict(torch.load(a / "best_surv_model.pth"), strict=True)
+    b = tmp_path / "cls"; b.mkdir()
+    log = _run_ranks(["--preop", "--classification", "--epochs", "2", "--synthetic_patients", "16", "--config", cfg], b)
+    assert log.count("epoch 2/2") == 1                                                                                  # rank 0 logs
+    MLP(32, 2, 12).load_state_dict(torch.load(b / "final_model.pth"), strict=True)
+    assert sorted(p.name for p in b.glob("synthetic_train_rank*.csv")) == ["synthetic_train_rank0.csv", "synthetic_train_rank1.csv"]
