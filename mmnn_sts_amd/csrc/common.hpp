@@ -98,6 +98,10 @@ __device__ __forceinline__ double stat_total(const double* base, int stride, int
   if (nrep == NREP) {
 #pragma unroll
     for (int r = 0; r < NREP; ++r) t += base[(long)r * stride + idx];
+  } else if (nrep <= 2) {
+    // both loads unconditional (replica 0 twice when there is one): a loop over a run-time count waits for each load in turn
+    const double t0 = base[idx], t1 = base[(nrep > 1 ? (long)stride : 0l) + idx];
+    t = (t + t0) + (nrep > 1 ? t1 : 0.0);
   } else {
     for (int r = 0; r < nrep; ++r) t += base[(long)r * stride + idx];
   }
@@ -143,6 +147,62 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwd& s, int c, float& p, flo
   p = (float)(g * rstd);
   q = (float)(-g * rstd * rstd * m2);
   r = (float)(g * rstd * rstd * m2 * mean - g * rstd * m1);
+}
+
+// The same coefficients in two steps for the latency-bound (small-extent) launches: `*_issue` only LOADS -- its results are not
+// touched until `*_finish`, so the caller can put the first chunk's operand loads between the two and the statistics' memory
+// round trip runs beside theirs instead of after it.  Training-mode statistics with at most two replicas (StatPtr::nrep <= 2: every
+// small-extent dense block); `c` must be a valid channel (callers clamp and discard).  Bit-identical to bn_fwd_coef / bn_bwd_coef.
+struct BnFwdRaw { double s0, s1, q0, q1; float g, b; };
+struct BnBwdRaw { double s0, s1, q0, q1, a0, a1, b0, b1; float g; };
+
+__device__ __forceinline__ void bn_fwd_issue(const BnFwd& s, int c, BnFwdRaw& r) {
+  const long i = s.st.off + c, i1 = (s.st.nrep > 1 ? (long)s.st.stride : 0l) + i;
+  r.s0 = s.st.sum[i]; r.s1 = s.st.sum[i1];
+  r.q0 = s.st.sq[i];  r.q1 = s.st.sq[i1];
+  r.g = s.gamma[c]; r.b = s.beta[c];
+}
+// (`pin`: an empty volatile asm that "rewrites" the loaded values where the arithmetic is meant to start.  Without it the compiler
+// hoists the first conversions and additions up to the loads and waits for them there -- ahead of the operand loads they were issued
+// early to overlap with.)
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+__device__ __forceinline__ void bn_fwd_finish(const BnFwd& s, BnFwdRaw& r, float& a, float& b, float& mean_f, float& rstd_f) {
+  pin(r.s0); pin(r.s1); pin(r.q0); pin(r.q1); pin(r.g); pin(r.b);
+  const bool two = s.st.nrep > 1;
+  const double mean = ((0.0 + r.s0) + (two ? r.s1 : 0.0)) * s.inv_count;
+  double var = ((0.0 + r.q0) + (two ? r.q1 : 0.0)) * s.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = rsqrt_var(var + (double)s.eps);
+  const double g = (double)r.g;
+  a = (float)(g * rstd);
+  b = (float)((double)r.b - mean * g * rstd);
+  mean_f = (float)mean;
+  rstd_f = (float)rstd;
+}
+__device__ __forceinline__ void bn_bwd_issue(const BnBwd& s, int c, BnBwdRaw& r) {
+  const long i = s.st.off + c, i1 = (s.st.nrep > 1 ? (long)s.st.stride : 0l) + i;
+  const long j = s.s.off + c, j1 = (s.s.nrep > 1 ? (long)s.s.stride : 0l) + j;
+  r.s0 = s.st.sum[i]; r.s1 = s.st.sum[i1];
+  r.q0 = s.st.sq[i];  r.q1 = s.st.sq[i1];
+  r.a0 = s.s.sum[j];  r.a1 = s.s.sum[j1];
+  r.b0 = s.s.sq[j];   r.b1 = s.s.sq[j1];
+  r.g = s.gamma ? s.gamma[c] : 1.f;
+}
+__device__ __forceinline__ void bn_bwd_finish(const BnBwd& s, BnBwdRaw& r, float& p, float& q, float& rr) {
+  pin(r.s0); pin(r.s1); pin(r.q0); pin(r.q1); pin(r.a0); pin(r.a1); pin(r.b0); pin(r.b1); pin(r.g);
+  const bool two = s.st.nrep > 1, two_s = s.s.nrep > 1;
+  const double mean = ((0.0 + r.s0) + (two ? r.s1 : 0.0)) * s.inv_count;
+  double var = ((0.0 + r.q0) + (two ? r.q1 : 0.0)) * s.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = rsqrt_var(var + (double)s.eps);
+  const double m1 = ((0.0 + r.a0) + (two_s ? r.a1 : 0.0)) * s.inv_count;
+  const double m2 = ((0.0 + r.b0) + (two_s ? r.b1 : 0.0)) * s.inv_count;
+  const double g = (double)r.g;
+  p = (float)(g * rstd);
+  q = (float)(-g * rstd * rstd * m2);
+  rr = (float)(g * rstd * rstd * m2 * mean - g * rstd * m1);
 }
 
 // counter-based uniform in [0,1): splitmix64 of (seed, layer, n, c)
@@ -206,6 +266,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// Every 64-byte line of the kernel-argument segment in ONE scalar-cache round trip, first thing in a kernel.  The argument
+// structs here are 200-560 bytes; the compiler places each `s_load` next to its first use, every line it touches for the first
+// time is a miss (the segment was written by the host a moment ago: cold in every cache) and the misses come one after the other --
+// five dependent waits before the first vector load of the convolution kernels, ~2 us of a 12 us small-extent launch
+// (tools/phase_trace.py, phase "load0 issue").  One asm statement: the destination registers must not be reused while a load
+// is in flight, so the wait sits inside it.  Twelve loads; the ones past the last line of the struct re-read that line.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+  constexpr int L = (BYTES + 63) / 64;
+  static_assert(L >= 1 && L <= 12, "argument struct larger than 768 bytes");
+#define MMNN_KOFF(i) ((i) < L ? (i) * 64 : (L - 1) * 64)
+  const auto k = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11;
+  asm volatile(
+      "s_load_dword %0, %12, %13\n\ts_load_dword %1, %12, %14\n\ts_load_dword %2, %12, %15\n\ts_load_dword %3, %12, %16\n\t"
+      "s_load_dword %4, %12, %17\n\ts_load_dword %5, %12, %18\n\ts_load_dword %6, %12, %19\n\ts_load_dword %7, %12, %20\n\t"
+      "s_load_dword %8, %12, %21\n\ts_load_dword %9, %12, %22\n\ts_load_dword %10, %12, %23\n\ts_load_dword %11, %12, %24\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10),
+        "=&s"(t11)
+      : "s"(k), "n"(MMNN_KOFF(0)), "n"(MMNN_KOFF(1)), "n"(MMNN_KOFF(2)), "n"(MMNN_KOFF(3)), "n"(MMNN_KOFF(4)), "n"(MMNN_KOFF(5)),
+        "n"(MMNN_KOFF(6)), "n"(MMNN_KOFF(7)), "n"(MMNN_KOFF(8)), "n"(MMNN_KOFF(9)), "n"(MMNN_KOFF(10)), "n"(MMNN_KOFF(11))
+      : "memory");
+#undef MMNN_KOFF
 }
 #endif  // __HIPCC__
 

@@ -62,6 +62,10 @@ struct FpropArgs {
   // one dword per 128-byte line of [pf_ptr, pf_ptr + pf_bytes) while their own first chunk is in flight, which pulls the range
   // into that XCD's L2 before the next kernel starts.
   const float* pf_ptr; unsigned pf_bytes;
+  // Filled in by launch_cfg (callers leave them zero): ceil(2^32 / d) for the divisors of the workgroup -> tile decomposition
+  // (3x3x3: tiles along W, H, D; 1x1x1: tiles per sample), 0 when d == 1.  q = mulhi(b, magic) is exact for b * d < 2^32 and is two
+  // scalar instructions; the compiler's sequence for a run-time divisor is ~25 dependent ones, three times over, ahead of the first load.
+  unsigned mg_w, mg_h, mg_d;
   // developer aid (tools/phase_trace.py): when non-null, thread 0 of the first 64 blocks of the launch stores shader-clock stamps
   // of its phases to trace[block * 16 + k]; null in normal operation
   unsigned long long* trace;
@@ -129,6 +133,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     if (tracing) a.trace[(blockIdx.x * (gridDim.z > 1 ? 2 : 1) + (blockIdx.z ? 1 : 0)) % 64 * 16 + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  kernarg_warm<sizeof(FpropArgs)>();
+  stamp(13);
   float pf_sink = 0.f, pf_sink2 = 0.f;                   // keep the prefetch loads alive (see FpropArgs::pf_ptr)
   const bool loader = SPEC && tid >= NL;                 // wave-uniform role
   const int ltid = loader ? tid - NL : tid;              // index within the role's thread set
@@ -153,24 +159,86 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     int b = blockIdx.x;
     // (Applying the same order to the 1x1x1 kernels, so that producer and consumer tiles share an XCD, measured no gain: r02.)
     if (TAPS == 27 && (gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
+    auto divmod = [](int& x, int d, unsigned magic) {      // x <- x / d, returns x % d
+      const int q = magic ? (int)__umulhi((unsigned)x, magic) : x;
+      const int r = x - q * d;
+      x = q;
+      return r;
+    };
     if (TAPS == 27) {
       const int nw = (a.W + TW - 1) / TW, nh = (a.H + TH - 1) / TH, nd = (a.D + TD - 1) / TD;
-      w0 = (b % nw) * TW; b /= nw;
-      h0 = (b % nh) * TH; b /= nh;
-      d0 = (b % nd) * TD; b /= nd;
+      w0 = divmod(b, nw, a.mg_w) * TW;
+      h0 = divmod(b, nh, a.mg_h) * TH;
+      d0 = divmod(b, nd, a.mg_d) * TD;
       n = b;
     } else {
       const int nt = (V + V_B - 1) / V_B;
-      v0_ = (b % nt) * V_B;
-      n = b / nt;
+      v0_ = divmod(b, nt, a.mg_w) * V_B;
+      n = b;
     }
   }
   const int m0 = blockIdx.y * M_B;
   const int rep = blockIdx.x & ((a.nrep > 0 ? a.nrep : NREP) - 1);
   // channel slice of this block (cross-block K-split): whole chunks [c_begin, c_end)
+  // (kz is a power of two -- launch_cfg doubles it -- so the slice bounds are shifts: the 64-bit run-time division this used to be
+  // is ~100 dependent instructions, twice, ahead of the first load of every launch)
   const int kz = gridDim.z, nch_all = (a.Cin + KC - 1) / KC;
-  const int c_begin = (int)((long)nch_all * blockIdx.z / kz) * KC;
-  const int c_end = min(a.Cin, (int)((long)nch_all * (blockIdx.z + 1) / kz) * KC);
+  const int kz_sh = __builtin_ctz((unsigned)kz);
+  const int c_begin = ((nch_all * (int)blockIdx.z) >> kz_sh) * KC;
+  const int c_end = min(a.Cin, ((nch_all * ((int)blockIdx.z + 1)) >> kz_sh) * KC);
+
+  // ---- small tiles: the loads the coefficients need go out FIRST (a handful per thread), the first chunks' operand loads follow,
+  // and the coefficient arithmetic (prologue_fast below) runs when the statistics are back -- memory returns in order, so it no
+  // longer waits behind the 50-110 KB of operands, and the operands no longer wait for it: one memory round trip where the phase
+  // trace of r03 showed three (tools/phase_trace.py: "prologue" 3.6k + "1st store" 3.3k cycles of a 27k-cycle 8^3 launch). ----
+  constexpr bool EARLY_K = (MT * NT == 1) || (TAPS == 27 && TW <= 16);          // the latency-bound tile shapes (see EARLY below)
+  constexpr bool MASK_E = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
+  static_assert(!EARLY_K || M_B <= NTHREADS, "one epilogue row per thread");
+  const int c_hi = min(cpad, c_begin + ((c_end - c_begin + KC - 1) / KC) * KC);   // end of this slice's coefficient range
+  bool fastp = EARLY_K && (c_hi - c_begin) <= NTHREADS;
+  if (PRO == PRO_BNRELU) fastp = fastp && a.bn_in.training && a.bn_in.st.nrep <= 2;
+  if (PRO == PRO_GRAD) fastp = fastp && a.gr_in.st.nrep <= 2 && a.gr_in.s.nrep <= 2;
+  if (MASK_E) fastp = fastp && a.ebn.training && a.ebn.st.nrep <= 2;
+  BnFwdRaw raw_in, raw_e;
+  BnBwdRaw raw_gr;
+  if (EARLY_K && fastp) {
+    const int pc = max(0, min(c_begin + tid, a.Cin - 1)), pm = max(0, min(m0 + tid, a.M - 1));   // clamped: the loads are unconditional
+    if (PRO == PRO_BNRELU) bn_fwd_issue(a.bn_in, pc, raw_in);
+    if (PRO == PRO_GRAD) bn_bwd_issue(a.gr_in, pc, raw_gr);
+    if (MASK_E) bn_fwd_issue(a.ebn, pm, raw_e);
+  }
+  stamp(14);
+  auto prologue_fast = [&]() {
+    const int c = c_begin + tid;
+    if (c < c_hi) {
+      if (PRO == PRO_BNRELU) {
+        float ca = 0.f, cb = 0.f, mu, rs;
+        bn_fwd_finish(a.bn_in, raw_in, ca, cb, mu, rs);
+        const bool ok = c < a.Cin;
+        coef[c] = ok ? ca : 0.f; coef[cpad + c] = ok ? cb : 0.f;
+      } else if (PRO == PRO_GRAD) {
+        float p = 0.f, q = 0.f, r = 0.f;
+        bn_bwd_finish(a.gr_in, raw_gr, p, q, r);
+        const bool ok = c < a.Cin;
+        const float sc = drop_scale(a.drop_in, n, c);
+        coef[c] = ok ? p * sc : 0.f; coef[cpad + c] = ok ? q * sc : 0.f; coef[2 * cpad + c] = ok ? r * sc : 0.f;
+      }
+    }
+    if (tid < M_B) {
+      const int m = tid;
+      float ea = 0.f, eb = 0.f, mu = 0.f, rs = 0.f, g = 0.f, ds = 1.f;
+      if (m0 + m < a.M) {
+        if (MASK_E) {
+          bn_fwd_finish(a.ebn, raw_e, ea, eb, mu, rs);
+          g = raw_e.g;
+        }
+        if (EPI == EPI_STORE_STATS) ds = drop_scale(a.drop_out, n, m0 + m);
+      }
+      ecoef[m] = ea; ecoef[M_B + m] = eb; ecoef[2 * M_B + m] = mu; ecoef[3 * M_B + m] = rs;
+      ecoef[4 * M_B + m] = g; ecoef[5 * M_B + m] = ds;
+    }
+    __syncthreads();
+  };
 
   // ---- per-channel prologue coefficients, per-row epilogue coefficients.  Called AFTER the first chunk's global loads have
   // been issued (fast path): the coefficients cost a memory round trip of their own (fp64 statistics) and are only needed when
@@ -372,6 +440,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     constexpr bool EARLY = (MT * NT == 1) || (TAPS == 27 && TW <= 16);
     const bool first_chunk_mine = (c_begin < c_end) && (!SPEC || loader);
     if (EARLY && first_chunk_mine) load_w(c_begin, stA);
+    stamp(15);
     {
       // 32-bit offsets: this path is only taken when KC * V < 2^30 (64-bit multiplies cost four instructions each, and this
       // set-up runs before the first load of every launch: 2.5 us of the 8^3 / 4^3 kernels in the phase trace)
@@ -498,7 +567,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       // loader waves fill buffer (k+1)&1 while compute waves consume buffer k&1; one barrier per chunk
       if (loader && c_begin < c_end) load_first(stA);
       stamp(1);
-      if (EARLY) prologue();
+      if (EARLY) { if (fastp) prologue_fast(); else prologue(); }
       prefetch_next_weights();
       stamp(2);
       if (loader && c_begin < c_end) store_chunk(c_begin, stA, 0);
@@ -516,7 +585,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
     } else if (PF == 1) {
       if (c_begin < c_end) load_first(stA);
       stamp(1);
-      if (EARLY) prologue();
+      if (EARLY) { if (fastp) prologue_fast(); else prologue(); }
       prefetch_next_weights();
       stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += KC) {
@@ -532,7 +601,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
       if (c_begin < c_end) load_first(stA);
       if (c_begin + KC < c_end) load_chunk(c_begin + KC, stB);
       stamp(1);
-      if (EARLY) prologue();
+      if (EARLY) { if (fastp) prologue_fast(); else prologue(); }
       prefetch_next_weights();
       stamp(2);
       for (int c0 = c_begin; c0 < c_end; c0 += 2 * KC) {
@@ -755,6 +824,56 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
 #if MMNN_KZ_FENCED
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every reading wave: drops this CU's stale L1 lines of the partial tiles
 #endif
+    if constexpr (KS > 1) {
+      // Every wave group takes 16 / KS accumulator rows of each tile and has ALL slices' loads in flight at once (slices past kz
+      // re-read the last one and add an exact zero): one memory round trip instead of kz / 2 dependent ones by the group-0 waves
+      // alone (phase "kz sum": 3.7k of a 27k-cycle launch at kz = 8).  Summed in slice order as before -- same bits -- and handed to
+      // the epilogue waves through the staging area, which is free since the barriers above.
+      constexpr int RP = 16 / KS;                       // rows per wave group
+      constexpr int ZB = (RP <= 4) ? 8 : 4;             // slices in flight: at most 32 loads per lane
+      float* xbuf = Xs;
+      if (!loader) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            float sacc[RP];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) sacc[q] = 0.f;
+            for (int z0 = 0; z0 < kz; z0 += ZB) {
+              float pz[ZB][RP];
+#pragma unroll
+              for (int z = 0; z < ZB; ++z) {
+                const int zc = min(z0 + z, kz - 1);
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                  const float* sp = part + (((long)zc * NSLOT + slot + i * NT + j) * 16 + kg * RP + q) * 64 + lane;
+#if MMNN_KZ_FENCED
+                  pz[z][q] = *sp;
+#else
+                  pz[z][q] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // global_load_dword ... sc1
+#endif
+                }
+              }
+#pragma unroll
+              for (int z = 0; z < ZB; ++z)
+#pragma unroll
+                for (int q = 0; q < RP; ++q) sacc[q] += (z0 + z < kz) ? pz[z][q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < RP; ++q) xbuf[((slot + i * NT + j) * 16 + kg * RP + q) * 64 + lane] = sacc[q];
+          }
+      }
+      __syncthreads();
+      if (kg == 0 && !loader) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = xbuf[((slot + i * NT + j) * 16 + r) * 64 + lane];
+      }
+    } else {
     if (kg == 0 && !loader) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -781,12 +900,13 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
           }
         }
     }
+    }
   }
 
   stamp(6);
   // the wide epilogue reuses the staging area: with an in-block K-split the group-0 waves were still reading their partners'
-  // accumulators from it (the cross-block path above has its own barriers)
-  if (C::WIDE && KS > 1 && kz == 1) __syncthreads();
+  // accumulators (kz == 1) or the summed slices (kz > 1) from it
+  if (C::WIDE && KS > 1) __syncthreads();
   // ================= epilogue =================
   float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
   float* red1 = red0 + WN * M_B;

@@ -4,12 +4,15 @@
 #pragma once
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "fprop.hpp"
 
 namespace mmnn {
 
 template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
-static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
+static int launch_cfg(const FpropArgs& a_in, hipStream_t stream) {
+  FpropArgs a = a_in;
   constexpr bool KZ_OK = (MT * NT == 1) || (TAPS == 27 && TW <= 16);   // only the small-extent tiles are ever short of blocks
   using C = FpropCfg<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
   auto kern = fprop_kernel<TAPS, PRO, EPI, WM, WN, KS, MT, NT, KC, TD, TH, TW, SPEC>;
@@ -30,6 +33,15 @@ static int launch_cfg(const FpropArgs& a, hipStream_t stream) {
   else tiles = (long)a.N * cdiv((long)a.D * a.H * a.W, C::V_B);
   const int mtiles = cdiv(a.M, C::M_B);
   MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31) && mtiles <= 65535, "fprop: grid out of range");
+  {
+    // divisors of the kernel's workgroup -> tile decomposition as multiply-high constants (FpropArgs::mg_*)
+    auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1ull) / (unsigned long long)d); };
+    long dw, dh = 1, dd = 1;
+    if (TAPS == 27) { dw = cdiv(a.W, TW); dh = cdiv(a.H, TH); dd = cdiv(a.D, TD); }
+    else dw = cdiv((long)a.D * a.H * a.W, C::V_B);
+    MMNN_REQUIRE(tiles * std::max(dw, std::max(dh, dd)) < (1l << 32), "fprop: tile count out of range for the multiply-high decomposition");
+    a.mg_w = magic(dw); a.mg_h = magic(dh); a.mg_d = magic(dd);
+  }
   // cross-block K-split: when the (voxel, row) tiles alone cannot fill the chip, slices of the channel axis become blocks too
   int kz = 1;
   static const bool kz_off = []() { const char* e = getenv("MMNN_NO_KZ"); return e && e[0] == '1'; }();   // debugging aid

@@ -46,7 +46,7 @@ for i in range(SLOTS):
             print(f"{i:3d}  wgrad{3 if taps == 27 else 1} M {M} Cin {cin} grid {gx},{gy},{gz}: tiles/block {m[6]:.0f} | first load+coef {m[0]:.0f} | per tile: store {m[1] / m[6]:.0f}  "
                   f"barrier {m[2] / m[6]:.0f}  load issue {m[3] / m[6]:.0f}  mfma {m[4] / m[6]:.0f}  barrier {m[5] / m[6]:.0f}  = {(m[1:6].sum()) / m[6]:.0f} cycles")
         continue
-    rows = []
+    rows, head = [], []
     for b in range(64):
         st = t[i, b]
         if st[0] == 0 or st[8] == 0:
@@ -58,7 +58,11 @@ for i in range(SLOTS):
                 if seq[j] == 0:
                     seq[j] = seq[j - 1]
         rows.append(np.diff(np.array(seq, dtype=np.float64)))
+        # inside "load0 issue": argument warm-up done / statistic loads issued / first weight loads issued, as offsets from the start
+        head.append([float(int(st[k]) - int(st[0])) if st[k] else 0.0 for k in (13, 14, 15)])
     if not rows:
         continue
     d = np.median(np.stack(rows), axis=0)
-    print(f"{i:3d}  {taps:4d} {pro:3d} {epi:3d} {M:4d} {cin:4d}  {gx:4d},{gy:2d},{gz:1d} {waves:5d} {kc:3d} | {d.sum():7.0f} | " + " | ".join(f"{v:7.0f}" for v in d))
+    h = np.median(np.stack(head), axis=0)
+    print(f"{i:3d}  {taps:4d} {pro:3d} {epi:3d} {M:4d} {cin:4d}  {gx:4d},{gy:2d},{gz:1d} {waves:5d} {kc:3d} | {d.sum():7.0f} | " + " | ".join(f"{v:7.0f}" for v in d)
+          + " || args %5.0f  stats issued %5.0f  weights issued %5.0f" % tuple(h))
