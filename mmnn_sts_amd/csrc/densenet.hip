@@ -147,7 +147,7 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
     if (b != nb - 1) p.o_pk_tr.push_back(cv.take((size_t)p.trans[b].cin * p.trans[b].cout * F));
   }
   // weight-gradient slabs
-  p.ns_conv0 = stem_wgrad_pick_splits(N, p.D0, p.H0, p.W0);
+  p.ns_conv0 = stem_wgrad_pick_splits(N, p.D0, p.H0, p.W0, cfg.in_channels);
   p.o_sl_conv0 = cv.take((size_t)p.ns_conv0 * cfg.in_channels * cfg.init_features * 352 * F);
   p.o_sl_c1.assign(nb, {}); p.o_sl_c2.assign(nb, {}); p.ns_c1.assign(nb, {}); p.ns_c2.assign(nb, {});
   p.o_sl_tr.clear(); p.ns_tr.clear();

@@ -202,10 +202,15 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   BnFwdRaw raw_in, raw_e;
   BnBwdRaw raw_gr;
   if (EARLY_K && fastp) {
-    const int pc = max(0, min(c_begin + tid, a.Cin - 1)), pm = max(0, min(m0 + tid, a.M - 1));   // clamped: the loads are unconditional
-    if (PRO == PRO_BNRELU) bn_fwd_issue(a.bn_in, pc, raw_in);
-    if (PRO == PRO_GRAD) bn_bwd_issue(a.gr_in, pc, raw_gr);
-    if (MASK_E) bn_fwd_issue(a.ebn, pm, raw_e);
+    // Only the waves that own a channel / a row load (a slice is 16-128 channels of a 512-thread block): memory returns in order, and
+    // eight waves' worth of redundant statistic loads ahead of the operand loads cost more than they hide.  Indices clamped inside a
+    // wave, values of padding channels discarded in prologue_fast.
+    const int pc = max(0, min(c_begin + tid, a.Cin - 1)), pm = max(0, min(m0 + tid, a.M - 1));
+    if (PRO != PRO_NONE && c_begin + (tid & ~63) < c_hi) {
+      if (PRO == PRO_BNRELU) bn_fwd_issue(a.bn_in, pc, raw_in);
+      if (PRO == PRO_GRAD) bn_bwd_issue(a.gr_in, pc, raw_gr);
+    }
+    if (MASK_E && (tid & ~63) < M_B) bn_fwd_issue(a.ebn, pm, raw_e);
   }
   stamp(14);
   auto prologue_fast = [&]() {

@@ -19,13 +19,18 @@ constexpr int SC_RS = 2 * SC_PO;           // 72
 constexpr int SC_CS = SC_TD * SC_ROWS * SC_RS;
 constexpr int SC_MAXC = 4;
 
-template <bool PAIR_C>
-__global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
+// r03: software-pipelined over kd.  The workgroups that share a CU start together and take identical time per phase, so they stay in
+// step for the whole launch: with one LDS buffer every one of them staged at the same moment, matrix pipe idle, and computed at the
+// same moment (measured with the phases switched off one at a time: 327 us of MFMA loop + 98 us of staging = the 429 us of the whole
+// kernel -- nothing overlapped, at two, three or four workgroups per CU alike).  Now a workgroup issues the global loads of slice kd+1
+// before its MFMA loop of slice kd, writes them to the OTHER buffer after it, and meets ONE barrier per slice.
+template <int CIN>
+__global__ void __launch_bounds__(256, 2) stem_conv_kernel(const StemConvArgs a) {
+  constexpr bool PAIR_C = (CIN % 2 == 0);
+  constexpr int KROWS = PAIR_C ? CIN * 49 : CIN * 56;
+  constexpr int XSZ = CIN * SC_CS, WSZ = KROWS * 64, BUFSZ = XSZ + WSZ;      // floats per buffer: [Cin][2][13][72] + [krows][64]
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int krows = PAIR_C ? a.Cin * 49 : a.Cin * 56;
-  float* Xs = smem;                           // [Cin][2][13][72]
-  float* Ws = Xs + a.Cin * SC_CS;             // [krows][64]
-  float* red = Ws + krows * 64;               // [4 waves][2][64] per-wave partial sums
+  float* red = smem;                          // [4 waves][2][64] per-wave partial sums: reuses buffer 0 after the last kd slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int Vi = a.D * a.H * a.W, Vo = a.Do * a.Ho * a.Wo;
   int b = blockIdx.x;
@@ -49,33 +54,97 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
     const int jt = wave * 2 + j;
     pos[j] = ((jt / SC_TH) * SC_ROWS + 2 * (jt % SC_TH)) * SC_RS + l31;
   }
-  const float* xn = a.x + (long)n * a.Cin * Vi;
+  const float* xn = a.x + (long)n * CIN * Vi;
 
-  for (int kd = 0; kd < 7; ++kd) {
-    __syncthreads();
-    // ---- stage input planes d_in = 2*(do0+dz) + kd - 3 ----
-    // 70 columns per row: the odd-Cin path pairs taps (kw, kw+1) across lane halves, so its zero-weight pad tap kw = 7
-    // reads parity-1 entry l31 + 3 <= 34; that entry must hold a finite value (0 * garbage-NaN would poison the tile).
-    const int items = a.Cin * SC_TD * SC_ROWS * 70;
-#pragma unroll 8
-    for (int it = tid; it < items; it += 256) {
-      const int ci = it % 70;
-      int row = it / 70;
-      const int r = row % SC_ROWS; row /= SC_ROWS;
-      const int dz = row % SC_TD;
-      const int c = row / SC_TD;
-      const int d = 2 * (do0 + dz) + kd - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
-      const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-      const float v = xn[ok ? (long)c * Vi + ((long)d * a.H + h) * a.W + w : 0];   // unconditional load, clamped address
-      Xs[c * SC_CS + (dz * SC_ROWS + r) * SC_RS + (ci & 1) * SC_PO + (ci >> 1)] = ok ? v : 0.f;
+  // ---- staging descriptors.  A wave takes whole input rows (c, dz, r): everything about a row -- bounds, base address, LDS row
+  // offset -- is wave-uniform and lives in scalar registers, and a lane only contributes its column: a byte offset and an LDS slot
+  // worked out once per block.  (The r02 form -- one flat item index per thread, (column, row, plane, channel) by division, 64-bit
+  // element offsets -- cost ~50 vector instructions per item, 3.6 per MFMA of the slice they feed, and vector instructions share the
+  // SIMD's issue port with the matrix pipe: tools/microbench/mfma_valu_overlap.hip, 4 per MFMA = 79 cycles instead of 64.)
+  // A row is 70 columns: lanes take column `lane` and, the first six, column `lane + 64` (the second load is issued by all lanes with
+  // a clamped address: uniform control flow keeps all loads of a slice in flight together).
+  // 70 columns per row: the odd-Cin path pairs taps (kw, kw+1) across lane halves, so its zero-weight pad tap kw = 7 reads parity-1
+  // entry l31 + 3 <= 34; that entry must hold a finite value (0 * garbage-NaN would poison the tile). ----
+  typedef const __attribute__((address_space(1))) float* gcf;
+  auto ldg = [](gcf base, unsigned byte_off) { return *(gcf)((const __attribute__((address_space(1))) char*)base + byte_off); };
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int wa = 2 * wo0 + lane - 3, wb_ = wa + 64;
+  const bool oka = (unsigned)wa < (unsigned)a.W, okb = lane < 6 && (unsigned)wb_ < (unsigned)a.W;
+  const unsigned offa = 4u * (unsigned)(oka ? wa : 2 * wo0), offb = 4u * (unsigned)(okb ? wb_ : 2 * wo0);   // clamped: the tile's first column
+  const int dsta = (lane & 1) * SC_PO + (lane >> 1), dstb = lane < 6 ? dsta + 32 : -1;                      // column ci -> parity plane, ci >> 1
+  constexpr int NROWS = CIN * SC_TD * SC_ROWS, RPW = (NROWS + 3) / 4;       // input rows of a slice; per wave
+  constexpr int W_IT = (KROWS * 16 + 255) / 256;                            // 16-byte weight items per thread
+  float va[RPW], vb[RPW];
+  f32x4 wr[W_IT];
+  // per row of this wave, once per block (scalar registers): byte offset of its first column at kd = 0, relative to the sample's first
+  // channel (host check: Cin * D*H*W * 4 < 2^31); LDS row offset; whether h lies inside the volume; its dz.  Per slice a row then costs
+  // an add and a few compares -- the first form of this staging re-derived (c, dz, r) and a 64-bit address per row and slice: ~60
+  // scalar instructions a row, 860 per wave and slice, on the ONE scalar unit the CU's sixteen waves share.
+  int rowoff0[RPW], lrow_[RPW];
+  unsigned hokm = 0, dzm = 0;
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int row = min(uwave + 4 * u, NROWS - 1);      // a wave's last row may not exist: re-read the last one, not stored
+    const int r = row % SC_ROWS, dz = (row / SC_ROWS) % SC_TD, c = row / (SC_ROWS * SC_TD);
+    const int h = 2 * ho0 + r - 3;
+    hokm |= ((unsigned)h < (unsigned)a.H ? 1u : 0u) << u;
+    dzm |= (unsigned)dz << u;
+    rowoff0[u] = 4 * (c * Vi + ((2 * (do0 + dz) - 3) * a.H + h) * a.W);
+    lrow_[u] = c * SC_CS + (dz * SC_ROWS + r) * SC_RS;
+  }
+  const int plane4 = 4 * a.H * a.W;
+  const int safe0 = 4 * ((2 * do0 * a.H + 2 * ho0) * a.W);   // a row that is always inside: the tile's own first row, channel 0
+  gcf xg = (gcf)xn;
+  unsigned rokm = 0;                                                        // bit u: row u of this wave lies inside the volume (wave-uniform)
+  auto load_kd = [&](int kd) {
+    const unsigned dok0 = (unsigned)(2 * do0 - 3 + kd) < (unsigned)a.D ? 1u : 0u, dok1 = (unsigned)(2 * do0 - 1 + kd) < (unsigned)a.D ? 1u : 0u;
+    rokm = 0;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const unsigned rok = ((hokm >> u) & 1u) & (((dzm >> u) & 1u) ? dok1 : dok0);
+      rokm |= rok << u;
+      const unsigned ro = (unsigned)(rok ? rowoff0[u] + kd * plane4 : safe0);
+      va[u] = ldg(xg, ro + offa);
+      vb[u] = ldg(xg, ro + offb);
     }
-    // ---- stage this kd's weight rows ----
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wp + (long)kd * krows * 64);
-    for (int it = tid; it < krows * 16; it += 256) reinterpret_cast<f32x4*>(Ws)[it] = wsrc[it];
-    __syncthreads();
+    // The weight loads are written out by hand: left to the compiler they sink below the MFMA loop, next to their first use, and the
+    // slice's memory round trip is paid in full (ISA of the first pipelined build).  The compiler does not count them in vmcnt, so they
+    // are issued AFTER the loads it does count (its waits then only ever wait longer than needed) and store_kd starts with vmcnt(0).
+    gcf wsrc = (gcf)(a.wp + (long)kd * KROWS * 64);
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const unsigned off = 16u * (unsigned)min(tid + i * 256, KROWS * 16 - 1);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wr[i]) : "v"(off), "s"(wsrc) : "memory");
+    }
+  };
+  auto store_kd = [&](int buf) {
+    float* Xs = smem + buf * BUFSZ;
+    float* Ws = Xs + XSZ;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+      const int row = uwave + 4 * u;
+      if (row < NROWS) {
+        const int lrow = lrow_[u];
+        const bool rok = (rokm >> u) & 1u;
+        Xs[lrow + dsta] = (rok && oka) ? va[u] : 0.f;
+        if (dstb >= 0) Xs[lrow + dstb] = (rok && okb) ? vb[u] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i)
+      if (tid + i * 256 < KROWS * 16) reinterpret_cast<f32x4*>(Ws)[tid + i * 256] = wr[i];
+  };
 
+  load_kd(0);
+  store_kd(0);
+  __syncthreads();
+  for (int kd = 0; kd < 7; ++kd) {
+    if (kd + 1 < 7) load_kd(kd + 1);
+    const float* Xs = smem + (kd & 1) * BUFSZ;
+    const float* Ws = Xs + XSZ;
     if (PAIR_C) {
-      for (int cp = 0; cp < a.Cin / 2; ++cp) {
+      for (int cp = 0; cp < CIN / 2; ++cp) {
         const float* xb = Xs + (2 * cp + half) * SC_CS;
         const float* wb = Ws + (2 * cp + half) * 49 * 64 + l31;
 #pragma unroll
@@ -93,7 +162,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
         }
       }
     } else {
-      for (int c = 0; c < a.Cin; ++c) {
+      for (int c = 0; c < CIN; ++c) {
         const float* xb = Xs + c * SC_CS + half * SC_PO;
         const float* wb = Ws + (c * 56 + half) * 64 + l31;
 #pragma unroll
@@ -111,9 +180,12 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemConvArgs a) {
         }
       }
     }
+    if (kd + 1 < 7) store_kd((kd + 1) & 1);     // the other buffer: its readers (slice kd - 1) are past the barrier below
+    __syncthreads();
   }
 
   // ---- epilogue: store + batch statistics ----
+  // (`red` lives in buffer 0, whose last readers -- slice 6 -- are past the loop's final barrier)
   float* outn = a.out + (long)n * a.M * Vo;
   long vox[2];
   bool vok[2];
@@ -167,13 +239,12 @@ int launch_stem_conv(const StemConvArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cin <= SC_MAXC, "stem conv: in_channels %d outside [1,%d]", a.Cin, SC_MAXC);
   MMNN_REQUIRE(a.M > 0 && a.M <= 64, "stem conv: init_features %d outside [1,64]", a.M);
   MMNN_REQUIRE(a.Do == (a.D - 1) / 2 + 1 && a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1, "stem conv: output extent mismatch");
-  MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "stem conv: volume too large");
+  MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30) && 4l * a.Cin * a.D * a.H * a.W < (1l << 31), "stem conv: volume too large");
   const int krows = stem_krows(a.Cin);
-  const size_t smem = sizeof(float) * ((size_t)a.Cin * SC_CS + (size_t)krows * 64 + 512);
+  const size_t smem = 2 * sizeof(float) * ((size_t)a.Cin * SC_CS + (size_t)krows * 64);   // two buffers (each >= 512 floats: room for the epilogue's partial sums)
   const long blocks = (long)a.N * cdiv(a.Do, SC_TD) * cdiv(a.Ho, SC_TH) * cdiv(a.Wo, SC_TW);
   MMNN_REQUIRE(blocks < (1l << 31) && smem <= 160 * 1024, "stem conv: launch out of range");
-  const bool pair_c = (a.Cin % 2 == 0);
-  auto kern = pair_c ? stem_conv_kernel<true> : stem_conv_kernel<false>;
+  auto kern = a.Cin == 1 ? stem_conv_kernel<1> : a.Cin == 2 ? stem_conv_kernel<2> : a.Cin == 3 ? stem_conv_kernel<3> : stem_conv_kernel<4>;
   MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   MMNN_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), smem, stream, a);
   MMNN_HIP(hipGetLastError());
@@ -449,9 +520,13 @@ constexpr int SW_XN = SW_PLANES * SW_PS;
 constexpr int SW_YS = 65;
 constexpr int SW_THREADS = 11 * 64;
 
+// Two LDS buffers and ONE barrier per tile (r03): a block owns its CU (11 waves, 112 registers), so with a single buffer every wave
+// sat through the store / barrier / load-issue phases together with the matrix pipe idle -- 18.4k cycles per tile against 12.3k of
+// MFMAs on the busiest SIMD.  Now the waves write tile t+1 into the other buffer between the two halves of their own MFMAs of tile t,
+// out of step with one another, and the loads of tile t+2 go out right after the barrier.
 __global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradArgs a) {
-  __shared__ float Xs[SW_XN];
-  __shared__ float Ys[64 * SW_YS];
+  __shared__ float Xs[2 * SW_XN];
+  __shared__ float Ys[2 * 64 * SW_YS];
   __shared__ float gcoef[3 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int Vi = a.D * a.H * a.W, Vo = a.Do * a.Ho * a.Wo;
@@ -475,95 +550,131 @@ __global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradA
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // ---- software pipeline: the (unconditional) global loads of tile t+1 are issued before the MFMA loop of tile t ----
-  constexpr int X_ITEMS = SW_PLANES * SW_ROWS * 37, Y_ITEMS = 64 * 64;
-  constexpr int X_IT = (X_ITEMS + SW_THREADS - 1) / SW_THREADS, Y_IT = (Y_ITEMS + SW_THREADS - 1) / SW_THREADS;
+  // ---- staging.  The (unconditional) global loads of tile t+1 are issued one barrier ahead of their LDS stores.  Everything a
+  // thread needs to know about its items is worked out ONCE: with 11 waves a CU the vector ALU is shared with the matrix pipe, and
+  // the r02 form (item -> (plane, row, column) by division, 64-bit element offsets, bounds per item; 489 vector instructions per
+  // tile and wave = 7.6 per MFMA) held the kernel at 92 cycles per MFMA instead of 64 (tools/microbench/mfma_valu_overlap.hip:
+  // 8 vector instructions per MFMA = 92).  Now: per-item LDS offset and 32-bit byte offset from a per-tile uniform base
+  // (`global_load_dword v, v_off, s[base]`), validity = two compares against per-tile scalars, tile origin advanced by carries. ----
+  typedef const __attribute__((address_space(1))) float* gcf;
+  auto ldg = [](gcf base, unsigned byte_off) { return *(gcf)((const __attribute__((address_space(1))) char*)base + byte_off); };
+  constexpr int XT = 19 * 37;                      // threads staging the input halo: 19 of its 81 (plane, row) pairs x 37 columns a pass
+  constexpr int X_IT = 5, Y_IT = 6;                // 81 / 19 passes;  64 x 64 gradient values / 704 threads
+  static_assert(X_IT * 19 >= SW_PLANES * SW_ROWS && Y_IT * SW_THREADS >= 64 * 64 && SW_THREADS >= XT, "staging passes");
+  constexpr int X_DUMMY = SW_XN - 1, Y_DUMMY = 64 * SW_YS - 1;   // padding words: where items that do not exist write their zero
+  static_assert(X_DUMMY > (SW_PLANES - 1) * SW_PS + (SW_ROWS - 1) * SW_RS + 36, "dummy word inside the used halo");
+  const int xci = tid % 37, xrow0 = tid / 37;
+  int x_pl[X_IT], x_r[X_IT], x_dst[X_IT];
+  unsigned x_rel[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int row = xrow0 + 19 * i, pl = row / SW_ROWS, r = row % SW_ROWS;
+    const bool live = tid < XT && row < SW_PLANES * SW_ROWS;
+    x_pl[i] = live ? pl : -1000;                   // fails every bounds test below
+    x_r[i] = r;
+    x_dst[i] = live ? pl * SW_PS + r * SW_RS + xci : X_DUMMY;
+    x_rel[i] = 4u * (unsigned)((pl * a.H + r) * a.W + xci);      // from the halo's corner (2 do0 - 3, 2 ho0 - 3, 2 wo0 - 3)
+  }
+  const unsigned x_safe = 4u * (unsigned)((3 * a.H + 3) * a.W + 3);   // the tile's own origin voxel: always inside the tensor
+  const int yt = tid & 63, ywx = yt % SW_TW, yhy = (yt / SW_TW) % SW_TH, ydz = yt / (SW_TW * SW_TH);
+  unsigned y_rel[Y_IT];
+  int y_dst[Y_IT];
+  unsigned y_mok = 0;
+#pragma unroll
+  for (int i = 0; i < Y_IT; ++i) {
+    const int m = wave + 11 * i;                   // item tid + i * 704 -> (m, t) = (it >> 6, it & 63)
+    const bool ok = m < a.M && m < 64;
+    y_mok |= (ok ? 1u : 0u) << i;
+    y_rel[i] = ok ? 4u * (unsigned)(m * Vo + (ydz * a.Ho + yhy) * a.Wo + ywx) : 0u;
+    y_dst[i] = m < 64 ? m * SW_YS + yt : Y_DUMMY;
+  }
   float xr[X_IT], y0[Y_IT], y1[Y_IT];
   unsigned okx = 0, oky = 0;
-  auto origin = [&](int tile, int& n, int& do0, int& ho0, int& wo0) {
-    int b = tile;
-    wo0 = (b % nw) * SW_TW; b /= nw;
-    ho0 = (b % nh) * SW_TH; b /= nh;
-    do0 = (b % nd) * SW_TD; b /= nd;
-    n = b;
-  };
-  auto load_tile = [&](int tile) {
-    int n, do0, ho0, wo0;
-    origin(tile, n, do0, ho0, wo0);
-    const float* xc = a.x + ((long)n * a.Cin + c) * Vi;
-    okx = oky = 0;
+  int ln, ld0, lh0, lw0;                            // origin of the NEXT tile to load
+  {
+    int b = t_begin;
+    lw0 = (b % nw) * SW_TW; b /= nw;
+    lh0 = (b % nh) * SW_TH; b /= nh;
+    ld0 = (b % nd) * SW_TD; b /= nd;
+    ln = b;
+  }
+  auto load_tile = [&]() {
+    const int dbase = 2 * ld0 - 3, hbase = 2 * lh0 - 3, wbase = 2 * lw0 - 3;
+    gcf xb = (gcf)(a.x + ((long)ln * a.Cin + c) * Vi + ((long)dbase * a.H + hbase) * a.W + wbase);
+    const long yo = (long)ln * a.M * Vo + ((long)ld0 * a.Ho + lh0) * a.Wo + lw0;
+    gcf yb0 = (gcf)(a.dz + yo), yb1 = (gcf)(a.y + yo);
+    const bool wok = (unsigned)(wbase + xci) < (unsigned)a.W;
+    okx = 0;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
-      const int it = tid + i * SW_THREADS;
-      const int ci = it % 37, r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
-      const int d = 2 * do0 + pl - 3, h = 2 * ho0 + r - 3, w = 2 * wo0 + ci - 3;
-      const bool ok = it < X_ITEMS && (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      const bool ok = wok && (unsigned)(dbase + x_pl[i]) < (unsigned)a.D && (unsigned)(hbase + x_r[i]) < (unsigned)a.H;
       okx |= (ok ? 1u : 0u) << i;
-      xr[i] = xc[ok ? ((long)d * a.H + h) * a.W + w : 0];
+      xr[i] = ldg(xb, ok ? x_rel[i] : x_safe);
     }
+    const bool vok = ld0 + ydz < a.Do && lh0 + yhy < a.Ho && lw0 + ywx < a.Wo;
+    oky = vok ? y_mok : 0u;
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
-      const int it = tid + i * SW_THREADS;
-      const int t = it & 63, m = it >> 6;
-      const int wx = t % SW_TW, hy = (t / SW_TW) % SW_TH, dz = t / (SW_TW * SW_TH);
-      const int d = do0 + dz, h = ho0 + hy, w = wo0 + wx;
-      const bool ok = it < Y_ITEMS && m < a.M && d < a.Do && h < a.Ho && w < a.Wo;
-      const long g = ok ? ((long)n * a.M + m) * Vo + ((long)d * a.Ho + h) * a.Wo + w : 0;
-      oky |= (ok ? 1u : 0u) << i;
-      y0[i] = a.dz[g];
-      y1[i] = a.y[g];
+      const unsigned o = vok ? y_rel[i] : 0u;
+      y0[i] = ldg(yb0, o);
+      y1[i] = ldg(yb1, o);
     }
+    // next tile, W fastest
+    lw0 += SW_TW;
+    if (lw0 >= nw * SW_TW) { lw0 = 0; lh0 += SW_TH; if (lh0 >= nh * SW_TH) { lh0 = 0; ld0 += SW_TD; if (ld0 >= nd * SW_TD) { ld0 = 0; ++ln; } } }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float* xs = Xs + buf * SW_XN;
+    float* ys = Ys + buf * (64 * SW_YS);
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) {
-      const int it = tid + i * SW_THREADS;
-      if (it < X_ITEMS) {
-        const int ci = it % 37, r = (it / 37) % SW_ROWS, pl = it / (37 * SW_ROWS);
-        Xs[pl * SW_PS + r * SW_RS + ci] = ((okx >> i) & 1u) ? xr[i] : 0.f;
-      }
-    }
+    for (int i = 0; i < X_IT; ++i) xs[x_dst[i]] = ((okx >> i) & 1u) ? xr[i] : 0.f;
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
-      const int it = tid + i * SW_THREADS;
-      if (it < Y_ITEMS) {
-        const int t = it & 63, m = it >> 6;
-        Ys[m * SW_YS + t] = ((oky >> i) & 1u) ? fmaf(gcoef[m], y0[i], fmaf(gcoef[64 + m], y1[i], gcoef[128 + m])) : 0.f;
-      }
+      const int m = min(wave + 11 * i, 63);
+      ys[y_dst[i]] = ((oky >> i) & 1u) ? fmaf(gcoef[m], y0[i], fmaf(gcoef[64 + m], y1[i], gcoef[128 + m])) : 0.f;
     }
   };
-  auto mfma_tile = [&]() {   // 32 k-steps x 2 output-channel tiles; operand reads one step ahead of the MFMAs
+  // k-steps [S0, S0 + 16) of a tile x 2 output-channel tiles; operand reads one step ahead of the MFMAs
+  auto mfma_half = [&](int buf, int S0) {
+    const float* xb = xl + buf * SW_XN;
+    const float* yb = yl + buf * (64 * SW_YS);
     auto rd = [&](int s, float (&av)[2], float& bv) {
-      bv = xl[(2 * (s / SW_TW)) * SW_RS + 2 * (s % SW_TW)];      // s < 32: dz = 0, hy = s/16, wx = s%16
-      av[0] = yl[s];
-      av[1] = yl[32 * SW_YS + s];
+      bv = xb[(2 * (s / SW_TW)) * SW_RS + 2 * (s % SW_TW)];      // s < 32: dz = 0, hy = s/16, wx = s%16
+      av[0] = yb[s];
+      av[1] = yb[32 * SW_YS + s];
     };
     auto mm = [&](const float (&av)[2], float bv) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv, acc[1], 0, 0, 0);
     };
     float a0[2], a1[2], b0, b1;
-    rd(0, a0, b0);
+    rd(S0, a0, b0);
 #pragma unroll
-    for (int s = 0; s < 32; s += 2) {
-      rd(s + 1, a1, b1);
+    for (int s = 0; s < 16; s += 2) {
+      rd(S0 + s + 1, a1, b1);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       mm(a0, b0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      if (s + 2 < 32) rd(s + 2, a0, b0);
+      if (s + 2 < 16) rd(S0 + s + 2, a0, b0);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       mm(a1, b1);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
   };
   __syncthreads();                                   // gcoef visible
-  if (t_begin < t_end) load_tile(t_begin);
+  if (t_begin < t_end) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    if (t_begin + 1 < t_end) load_tile();
+  }
   for (int tile = t_begin; tile < t_end; ++tile) {
-    store_tile();
+    const int cur = (tile - t_begin) & 1;
+    mfma_half(cur, 0);
+    if (tile + 1 < t_end) store_tile(cur ^ 1);       // loaded one barrier ago; the other buffer's readers are past that barrier too
+    mfma_half(cur, 16);
     __syncthreads();
-    if (tile + 1 < t_end) load_tile(tile + 1);
-    mfma_tile();
-    __syncthreads();
+    if (tile + 2 < t_end) load_tile();
   }
   float* out = a.slab + (long)split * a.slab_stride + (long)c * a.M * 352;
 #pragma unroll
@@ -575,9 +686,11 @@ __global__ void __launch_bounds__(SW_THREADS) stem_wgrad_kernel(const StemWgradA
     }
 }
 
-int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo) {
+int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo, int Cin) {
   const long ntiles = (long)N * cdiv(Do, SW_TD) * cdiv(Ho, SW_TH) * cdiv(Wo, SW_TW);
-  long s = 128;
+  // grid = splits x input channels, one 11-wave block per CU: 256 blocks in all (r03: a fixed 128 left half the chip idle for the
+  // single-channel encoders -- 472 us for half the work of the 2-channel fusion stem's 497 us)
+  long s = Cin >= 1 && Cin <= 8 ? 256 / Cin : 32;
   if (s > ntiles / 2) s = ntiles / 2;
   return s < 1 ? 1 : (int)s;
 }
@@ -585,6 +698,8 @@ int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo) {
 int launch_stem_wgrad(const StemWgradArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cin <= 65535 && a.M > 0 && a.M <= 64, "stem wgrad: bad extent");
   MMNN_REQUIRE(a.nsplit >= 1 && a.slab_stride >= (long)a.Cin * a.M * 352, "stem wgrad: bad slab layout");
+  // the kernel addresses a tile's operands with 32-bit byte offsets from a per-tile base
+  MMNN_REQUIRE(4l * a.M * a.Do * a.Ho * a.Wo < (1l << 32) && 4l * (9l * a.H + 9) * a.W < (1l << 32), "stem wgrad: extent too large for 32-bit tile offsets");
   MMNN_LAUNCH(stem_wgrad_kernel, dim3(a.nsplit, a.Cin), dim3(SW_THREADS), 0, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;

@@ -49,6 +49,6 @@ struct StemWgradArgs {
   float* slab; long slab_stride; int nsplit;   // slab[split][c][m][352]  (tap = kd*49 + kh*7 + kw < 343)
 };
 int launch_stem_wgrad(const StemWgradArgs& a, hipStream_t stream);
-int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo);
+int stem_wgrad_pick_splits(int N, int Do, int Ho, int Wo, int Cin);
 
 }  // namespace mmnn
