@@ -172,9 +172,9 @@ int plan_build(Plan& p, const NetCfg& cfg, int N, int D, int H, int W) {
       int pairs = 0;
       {
         const int g0 = (cfg.block_layers[b] - 1 - l) / p.wg_group[b];          // groups are formed from the LAST layer downwards
-        const int cw = wgrad1_channel_width(ci);
+        const int cw = wgrad1_channel_width(ci, p.Vb[b]);
         for (int k = 0; k < cfg.block_layers[b]; ++k)
-          if ((cfg.block_layers[b] - 1 - k) / p.wg_group[b] == g0 && wgrad1_channel_width(p.layers[b][k].cin) == cw)
+          if ((cfg.block_layers[b] - 1 - k) / p.wg_group[b] == g0 && wgrad1_channel_width(p.layers[b][k].cin, p.Vb[b]) == cw)
             pairs += cdiv(p.layers[b][k].cin, cw);
       }
       const int s1 = wgrad_pick_splits(1, N, p.Db[b], p.Hb[b], p.Wb[b], p.mid, ci, pairs);
@@ -756,7 +756,8 @@ int plan_backward_range(Plan& p, const float* params, const float* x, char* ws, 
       if (rc2) return rc2;
       for (int i = 0; i < np;) {       // conv1: runs of equal channel-group width (monotonic in the layer index)
         int j = i + 1;
-        while (j < np && wgrad1_channel_width(pend[j].w1.Cin) == wgrad1_channel_width(pend[i].w1.Cin)) ++j;
+        const long vb = (long)pend[i].w1.D * pend[i].w1.H * pend[i].w1.W;
+        while (j < np && wgrad1_channel_width(pend[j].w1.Cin, vb) == wgrad1_channel_width(pend[i].w1.Cin, vb)) ++j;
         if (j - i > 1) {
           for (int k = i; k < j; ++k) host[j - 1 - k] = pend[k].w1;
           ScopedTimer t(p, T_CONV1_WGRAD, pend[i].b, side2);

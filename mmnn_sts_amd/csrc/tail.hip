@@ -43,9 +43,9 @@ __global__ void __launch_bounds__(256) gap_kernel(const GapArgs a) {   // grid (
   if (lane == 0) a.pooled[(long)n * a.C + c] = s / (float)a.V;
 }
 
-__global__ void __launch_bounds__(256) gap_linear_kernel(const GapArgs a) {   // one block; wave per output element
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int o = wave; o < a.N * a.F; o += 4) {
+__global__ void __launch_bounds__(256) gap_linear_kernel(const GapArgs a) {   // a wave per output element (r03: over a grid, not one block:
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                 // 256 dependent dot products in a row were 31 us of every step)
+  for (int o = blockIdx.x * 4 + wave; o < a.N * a.F; o += 4 * gridDim.x) {
     const int n = o / a.F, f = o % a.F;
     float s = 0.f;
     for (int c = lane; c < a.C; c += 64) s += a.pooled[(long)n * a.C + c] * a.w[(long)f * a.C + c];
@@ -328,9 +328,11 @@ __global__ void __launch_bounds__(256) cox_kernel(const CoxArgs a) {   // ONE bl
   const int N = a.N, tid = threadIdx.x;
   __shared__ float sh_g, sh_w;
   __shared__ float pl[64];                              // per-problem losses (H*C <= 64)
+  __shared__ float lds_scratch[4 * 1024];               // small batches: the serial part below is a chain of dependent accesses
+  float* const scratch = N <= 1024 ? lds_scratch : a.scratch;
   for (int pb = 0; pb < a.H * a.C; ++pb) {
     const int h = pb / a.C, c = pb % a.C;
-    float* hs = a.scratch;                              // sorted log-hazards
+    float* hs = scratch;                                // sorted log-hazards
     float* ws = hs + N;                                 // sorted weights
     float* cs = ws + N;                                 // cumsum / later suffix sums
     int* pos = reinterpret_cast<int*>(cs + N);          // original index of sorted slot
@@ -471,7 +473,7 @@ int mmnn_gap_linear_forward(int32_t n, int32_t c, int32_t v, int32_t f, const fl
   GapArgs a{n, c, v, f, h, w, b, pooled, out, p, seed, training};
   hipStream_t s = static_cast<hipStream_t>(stream);
   MMNN_LAUNCH(gap_kernel, dim3(cdiv(c, 4), n), dim3(256), 0, s, a);
-  MMNN_LAUNCH(gap_linear_kernel, dim3(1), dim3(256), 0, s, a);
+  MMNN_LAUNCH(gap_linear_kernel, dim3(std::min(cdiv((long)n * f, 4), 1024)), dim3(256), 0, s, a);
   MMNN_HIP(hipGetLastError());
   return 0;
 }

@@ -13,8 +13,14 @@ static void wg3_tile(int W, int& TD, int& TH, int& TW) {
 }
 
 // channel-group width: 8 waves x 32 channels from 256 input channels on, else 4 waves (2-wave blocks spent more time staging the
-// 128-row dOut operand than multiplying; with 4 waves the ones beyond Cin just help staging)
-static int wg1_wc(int Cin) { static const int thr = [] { const char* e = getenv("MMNN_WG1_WC8_FROM"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }(); return Cin >= thr ? 8 : 4; }
+// 128-row dOut operand than multiplying; with 4 waves the ones beyond Cin just help staging).  Below 32^3 voxels the wide group already
+// pays from 97 channels on (r03, 16^3: all twelve layers of block 2 in one 8-wave launch 146 us against 159 us in two launches; at
+// 32^3 the same choice costs 340 against 281 us).
+static int wg1_wc(int Cin, long V) {
+  static const int thr_env = [] { const char* e = getenv("MMNN_WG1_WC8_FROM"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int thr = thr_env > 0 ? thr_env : (V >= 32768 ? 256 : 97);
+  return Cin >= thr ? 8 : 4;
+}
 
 int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int batch) {
   if (batch < 1) batch = 1;      // layers that share one launch: the block budget below is that of the whole launch
@@ -31,7 +37,7 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
   }
   const long V = (long)D * H * W;
   const long nchunks = (long)N * cdiv(V, 64);
-  const int wc = wg1_wc(Cin);
+  const int wc = wg1_wc(Cin, V);
   // Each block owns a (128 x 32*wc) tile of the weight gradient and loops over its share of the 64-voxel chunks.  The kernel is
   // HBM-heavy at block 1 (every (layer, channel group) pair re-reads the 128-row dOut operand: ~0.9 GB per launch), so what
   // matters is balance: ~2048 equal blocks per launch = four rounds of two blocks per CU measured best (r02, after the loads left
@@ -48,7 +54,7 @@ int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int 
   return s < 1 ? 1 : (int)s;
 }
 
-int wgrad1_channel_width(int Cin) { return 32 * wg1_wc(Cin); }
+int wgrad1_channel_width(int Cin, long V) { return 32 * wg1_wc(Cin, V); }
 
 // kernel translation units
 int wgrad3_launch(const WgradArgs& a, int pro_x, hipStream_t s);
@@ -71,10 +77,10 @@ int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev, int count,
     MMNN_REQUIRE(a.nsplit >= 1 && a.nsplit <= 65535, "wgrad: bad split count %d", a.nsplit);
     MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");
     MMNN_REQUIRE(taps == 27 ? a.M <= 32 : a.M <= 128, "wgrad batch: %d output channels exceed one block row", a.M);
-    MMNN_REQUIRE(taps == 27 || wg1_wc(a.Cin) == wg1_wc(f.Cin), "wgrad batch: layer %d needs another channel-group width", i);
+    MMNN_REQUIRE(taps == 27 || wg1_wc(a.Cin, (long)a.D * a.H * a.W) == wg1_wc(f.Cin, (long)f.D * f.H * f.W), "wgrad batch: layer %d needs another channel-group width", i);
   }
   if (taps == 27) return wgrad3_launch_batched(host, dev, count, seed, stream);
-  return wgrad1_launch_batched(host, dev, count, seed, wg1_wc(f.Cin), stream);
+  return wgrad1_launch_batched(host, dev, count, seed, wg1_wc(f.Cin, (long)f.D * f.H * f.W), stream);
 }
 
 int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream) {
@@ -87,7 +93,7 @@ int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream) {
   MMNN_REQUIRE(taps != 27 || a.M <= 32, "wgrad: the 3x3x3 kernel handles at most 32 output channels (growth rate), got %d", a.M);
   MMNN_REQUIRE(a.slab_stride >= (long)taps * a.M * a.Cin, "wgrad: slab stride too small");
   MMNN_REQUIRE(pro_x == PRO_BNRELU || pro_x == PRO_NONE, "wgrad: unsupported input prologue %d", pro_x);
-  return taps == 27 ? wgrad3_launch(a, pro_x, stream) : wgrad1_launch(a, pro_x, wg1_wc(a.Cin), stream);
+  return taps == 27 ? wgrad3_launch(a, pro_x, stream) : wgrad1_launch(a, pro_x, wg1_wc(a.Cin, (long)a.D * a.H * a.W), stream);
 }
 
 }  // namespace mmnn

@@ -37,9 +37,9 @@ struct WgradArgs {
 int launch_wgrad(const WgradArgs& a, int taps, int pro_x, hipStream_t stream);
 // `count` layers of identical extent (N, D, H, W), M and prologue in one launch.  host: the arguments (validated here);
 // dev_table: the same `count` entries in device memory (already uploaded); seed: this step's dropout seed (overrides drop.seed).
-// For taps == 1 every entry must select the same channel-group width (wgrad1_channel_width(Cin)).
+// For taps == 1 every entry must select the same channel-group width (wgrad1_channel_width(Cin, V)).
 int launch_wgrad_batched(const WgradArgs* host, const WgradArgs* dev_table, int count, uint64_t seed, int taps, int pro_x, hipStream_t stream);
-int wgrad1_channel_width(int Cin);   // input channels per block of the 1x1x1 kernel: 64, 128 or 256
+int wgrad1_channel_width(int Cin, long V);   // input channels per block of the 1x1x1 kernel (128 or 256) at V voxels per sample
 int wgrad_pick_splits(int taps, int N, int D, int H, int W, int M, int Cin, int batch = 1);   // batch: layers sharing the launch
 
 #if defined(__HIPCC__)
