@@ -95,7 +95,10 @@ struct FpropCfg {
   static_assert(TD * TH * TW == V_B, "tile volume must equal the block's voxel count");
   static_assert(KC % 2 == 0 && (KC / 2) % KS == 0, "channel-pair count of a chunk must be a multiple of the K-split");
   static constexpr int STAGE = KC * XS + KC * TAPS * M_B;                       // floats: activations + weights of a chunk
-  static constexpr int REDN = (KS - 1) * WM * WN * MT * NT * 1024;              // floats: cross-group accumulator reduction
+  // small tiles (one accumulator per wave, K split over wave groups): every group keeps 16 / KS rows of the tile from the in-block
+  // reduction to the stores (fprop_kernel, "distributed tail"); all KS groups' tiles pass through LDS
+  static constexpr bool DIST = (MT * NT == 1) && KS > 1 && !SPEC;
+  static constexpr int REDN = (DIST ? KS : KS - 1) * WM * WN * MT * NT * 1024;   // floats: cross-group accumulator reduction
   static constexpr int BUF0 = ((SPEC ? 2 : 1) * STAGE) > REDN ? ((SPEC ? 2 : 1) * STAGE) : REDN;
   // wide mask epilogue (see fprop_kernel): one 32 x 36 float transposition tile per wave, in the staging area after the K loop
   // (forward 3x3x3 tiles with two epilogue waves -- the 16^3 layers -- measured 1.8 us slower in the wide form: direct form kept)
@@ -115,6 +118,39 @@ __device__ __forceinline__ float pro_apply(const float* coef, int cpad, int c, f
   if (PRO == PRO_BNRELU) return fmaxf(fmaf(coef[c], x0, coef[cpad + c]), 0.f);
   if (PRO == PRO_GRAD) return fmaf(coef[c], x0, fmaf(coef[cpad + c], x1, coef[2 * cpad + c]));
   return x0;
+}
+
+// Sum each of R (2, 4 or 8) per-lane values over the 32 lanes of a wave half (half_reduce16 for fewer registers): log2(R) exchange-and-halve
+// steps, then plain butterflies.  On return every lane of a half holds the total of register index (l31 >> (5 - log2 R)).
+template <int R>
+__device__ __forceinline__ float half_reduce_n(const float (&v)[R], int lane) {
+  static_assert(R == 2 || R == 4 || R == 8, "half_reduce_n: 2, 4 or 8 registers");
+  float w[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) w[r] = v[r];
+  if (R >= 8) {
+    const bool b = lane & 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float send = b ? w[r] : w[r + 4], keep = b ? w[r + 4] : w[r]; w[r] = keep + swz_xor<16>(send); }
+  }
+  if (R >= 4) {
+    constexpr int X = (R == 8) ? 8 : 16;
+    const bool b = lane & X;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { const float send = b ? w[r] : w[r + 2], keep = b ? w[r + 2] : w[r]; w[r] = keep + swz_xor<X>(send); }
+  }
+  {
+    constexpr int X = (R == 8) ? 4 : (R == 4 ? 8 : 16);
+    const bool b = lane & X;
+    const float send = b ? w[0] : w[1], keep = b ? w[1] : w[0];
+    w[0] = keep + swz_xor<X>(send);
+  }
+  float t = w[0];
+  if (R <= 2) t += swz_xor<8>(t);
+  if (R <= 4) t += swz_xor<4>(t);
+  t += swz_xor<2>(t);
+  t += swz_xor<1>(t);
+  return t;
 }
 
 template <int TAPS, int PRO, int EPI, int WM, int WN, int KS, int MT, int NT, int KC, int TD, int TH, int TW, bool SPEC = false>
@@ -757,6 +793,144 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   }
 
   stamp(3);
+  float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
+  float* red1 = red0 + WN * M_B;
+  const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
+  if constexpr (C::DIST) {
+    // ================= distributed tail of the small tiles (r03).  One accumulator tile per wave, the K axis split over KS wave
+    // groups.  The r02 tail funnelled everything through the group-0 waves: they summed (KS - 1) x 16 rows from LDS, published 16 rows,
+    // summed the K-split slices and ran the whole epilogue while seven of eight waves waited (phase trace: 1.3k + 3.4k + 2.2k + 3.7k
+    // cycles of a 23k-cycle 8^3 launch).  Here every group keeps 16 / KS rows of its tile from the in-block reduction through the
+    // cross-workgroup hand-off to the stores; sums are taken in the same order as before (group order, then slice order). =======
+    constexpr int RP = 16 / KS, NSLOT = WM * WN;
+    constexpr bool MASK = (EPI == EPI_MASK_STORE || EPI == EPI_MASK_ACCUM);
+    float* rbuf = Xs;                                   // staging buffers are free after the last barrier
+    const int slot = wm * WN + wn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rbuf[((kg * NSLOT + slot) * 16 + r) * 64 + lane] = acc[0][0][r];
+    __syncthreads();
+    float my[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      float t = rbuf[((0 * NSLOT + slot) * 16 + kg * RP + q) * 64 + lane];
+#pragma unroll
+      for (int g = 1; g < KS; ++g) t += rbuf[((g * NSLOT + slot) * 16 + kg * RP + q) * 64 + lane];
+      my[q] = t;
+    }
+    stamp(4);
+    if (kz > 1) {
+      // cross-workgroup K-split, as in the general tail below (write-through partials, drained, ticket; the last arriver reads
+      // with sc1 loads) -- but every wave publishes and sums its own rows
+      const long tile_id = blockIdx.x + (long)gridDim.x * blockIdx.y;
+      float* part = a.kz_part + (tile_id * kz) * NSLOT * 1024;
+#pragma unroll
+      for (int q = 0; q < RP; ++q) {
+        float* dst = part + (((long)blockIdx.z * NSLOT + slot) * 16 + kg * RP + q) * 64 + lane;
+#if MMNN_KZ_FENCED
+        *dst = my[q];
+#else
+        __hip_atomic_store(dst, my[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_store_dword ... sc1
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores before the barrier
+      __syncthreads();
+      unsigned* ticket = reinterpret_cast<unsigned*>(ecoef + C::ECOEF * M_B);
+      if (tid == 0) {
+#if MMNN_KZ_FENCED
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // cumulative over the barrier: publishes the whole workgroup's stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        *ticket = __hip_atomic_fetch_add(a.kz_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      stamp(5);
+      const unsigned arrived = *ticket;
+      if (arrived != (unsigned)(kz - 1)) return;            // not the last slice of this tile: done
+      if (tid == 0) __hip_atomic_store(a.kz_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#if MMNN_KZ_FENCED
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      constexpr int ZB = (RP <= 4) ? 8 : 4;               // slices in flight: at most 32 loads per lane
+#pragma unroll
+      for (int q = 0; q < RP; ++q) my[q] = 0.f;
+      for (int z0 = 0; z0 < kz; z0 += ZB) {
+        float pz[ZB][RP];
+#pragma unroll
+        for (int z = 0; z < ZB; ++z) {
+          const int zc = min(z0 + z, kz - 1);
+#pragma unroll
+          for (int q = 0; q < RP; ++q) {
+            const float* sp = part + (((long)zc * NSLOT + slot) * 16 + kg * RP + q) * 64 + lane;
+#if MMNN_KZ_FENCED
+            pz[z][q] = *sp;
+#else
+            pz[z][q] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // global_load_dword ... sc1
+#endif
+          }
+        }
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+#pragma unroll
+          for (int q = 0; q < RP; ++q) my[q] += (z0 + z < kz) ? pz[z][q] : 0.f;
+      }
+    }
+    stamp(6);
+    // ---- epilogue of this wave's rows: register q holds row acc_row(kg * RP + q, half) of tile (wm, wn), voxel l31 ----
+    int vox; bool vok;
+    {
+      const int t = wn * 32 + l31;
+      if (TAPS == 27) {
+        const int wx = t % TW, hy = (t / TW) % TH, dz = t / (TW * TH);
+        const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+        vok = d < a.D && h < a.H && w < a.W;
+        vox = (d * a.H + h) * a.W + w;
+      } else {
+        vox = v0_ + t;
+        vok = vox < V;
+      }
+    }
+    int ml[RP]; bool ok[RP]; unsigned off[RP];
+    float xe[MASK ? RP : 1], go[(EPI == EPI_MASK_ACCUM) ? RP : 1];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      ml[q] = wm * 32 + acc_row(kg * RP + q, half);
+      ok[q] = vok && (m0 + ml[q]) < a.M;
+      off[q] = ok[q] ? (unsigned)(m0 + ml[q]) * (unsigned)V + (unsigned)vox : 0u;     // unconditional loads (clamped), before any store (aliasing)
+      if (MASK) xe[MASK ? q : 0] = exn[off[q]];
+      if (EPI == EPI_MASK_ACCUM) go[(EPI == EPI_MASK_ACCUM) ? q : 0] = outn[off[q]];
+    }
+    float s0[RP], s1[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+      float val = my[q], t0 = 0.f, t1 = 0.f;
+      if (EPI == EPI_STORE) {
+        if (ok[q]) outn[off[q]] = val;
+      } else if (EPI == EPI_STORE_STATS) {
+        val *= ecoef[5 * M_B + ml[q]];
+        if (ok[q]) { outn[off[q]] = val; t0 = val; t1 = val * val; }
+      } else {
+        if (ok[q]) {
+          const float x = xe[MASK ? q : 0];
+          const float pre = fmaf(ecoef[ml[q]], x, ecoef[M_B + ml[q]]);
+          const float z = pre > 0.f ? val : 0.f;
+          const float xh = (x - ecoef[2 * M_B + ml[q]]) * ecoef[3 * M_B + ml[q]];
+          t0 = z; t1 = z * xh;
+          if (EPI == EPI_MASK_STORE) outn[off[q]] = z;
+          else outn[off[q]] = go[(EPI == EPI_MASK_ACCUM) ? q : 0] + ecoef[4 * M_B + ml[q]] * z;
+        }
+      }
+      s0[q] = t0; s1[q] = t1;
+    }
+    if (want_sums) {
+      const float r0 = half_reduce_n<RP>(s0, lane), r1 = half_reduce_n<RP>(s1, lane);
+      constexpr int SH = (RP == 8) ? 2 : (RP == 4 ? 3 : 4);      // lanes l31 >> SH share a total: the first of each group writes it
+      if ((l31 & ((1 << SH) - 1)) == 0) {
+        const int mrow = wm * 32 + acc_row(kg * RP + (l31 >> SH), half);
+        red0[wn * M_B + mrow] = r0;
+        red1[wn * M_B + mrow] = r1;
+      }
+    }
+  } else {
   // ================= cross-group reduction of the accumulators (K-split) =================
   if (KS > 1) {
     float* rbuf = Xs;   // staging buffers are free after the last barrier
@@ -913,9 +1087,6 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
   // accumulators (kz == 1) or the summed slices (kz > 1) from it
   if (C::WIDE && KS > 1) __syncthreads();
   // ================= epilogue =================
-  float* red0 = ecoef + 6 * M_B;            // [WN][M_B] partial sums, one writer per slot (no LDS atomics: reproducible)
-  float* red1 = red0 + WN * M_B;
-  const bool want_sums = (EPI == EPI_STORE_STATS) ? (a.st_out.sum != nullptr) : (EPI != EPI_STORE);
 
   int vox[NT];
   bool vok[NT];
@@ -1102,6 +1273,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64 * (SPEC ? 2 : 1)) fprop_kernel
         red1[wn * M_B + ml] = r1;
       }
     }
+  }
   }
   }
   }

@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const MlpArgs a) {
     for (int e = tid; e < a.N * O; e += 256) {       // z = x W^T + b   (kept in xhat for now)
       const int n = e / O, o = e % O;
       float s = a.b[i][o];
-      for (int k = 0; k < D; ++k) s = fmaf(x[n * D + k], a.w[i][o * D + k], s);
+#pragma unroll 8
+      for (int k = 0; k < D; ++k) s = fmaf(x[n * D + k], a.w[i][o * D + k], s);     // (unrolled: eight independent loads in flight, same summation order)
       xhat[e] = s;
     }
     __syncthreads();
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const MlpArgs a) {
       for (int e = tid; e < a.N * D; e += 256) {     // dx = dz W
         const int n = e / D, k = e % D;
         float s = 0.f;
+#pragma unroll 8
         for (int o = 0; o < O; ++o) s = fmaf(dz[n * O + o], a.w[i][o * D + k], s);
         gnext[e] = s;
       }

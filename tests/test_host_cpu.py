@@ -191,8 +191,9 @@ def test_kz_handoff_isa():
     """the fence-free cross-workgroup K-split hand-off (csrc/fprop.hpp, MMNN_KZ_FENCED == 0) is only valid if the partial
     tiles really leave with write-through stores and are read back with L1-bypassing loads.  Disassemble the gfx950 code objects of the
     convolution translation units and check, for every kernel that takes a ticket (a returning agent-scope global_atomic_add), that
-    `global_store_dword ... sc1` precedes it (16 per accumulator tile) and `global_load_dword ... sc1` follows it (every wave group
-    reads 16 / KS rows of up to 8 slices: at least 16 in the code of a kernel)."""
+    `global_store_dword ... sc1` precedes it and `global_load_dword ... sc1` follows it (every wave group publishes its 16 / KS rows of
+    the tile -- 16 where one group holds the whole tile -- and reads them back from up to 8 slices: at least 2 stores and 16 loads in
+    the code of a kernel)."""
     import re
     import shutil
     import tempfile
@@ -221,7 +222,7 @@ def test_kz_handoff_isa():
                 t = tickets[0]
                 st = sum(1 for l in lines[:t] if "global_store_dword " in l and " sc1" in l)
                 ld = sum(1 for l in lines[t:] if "global_load_dword " in l and " sc1" in l)
-                assert st >= 16 and ld >= 16, (o, name[:80], st, ld)
+                assert st >= 2 and ld >= 16, (o, name[:80], st, ld)
                 checked += 1
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
