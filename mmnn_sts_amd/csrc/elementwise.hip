@@ -225,8 +225,18 @@ __global__ void __launch_bounds__(256) finalize_kernel(const GradJob* jobs, floa
         const int c = (int)(mc % j.C), m = (int)(mc / j.C);
         si = ((long)c * j.M + m) * 352 + tap;
       }
+      // eight slabs' loads in flight per round trip, added in slab order as before (a plain loop over the run-time count waits for
+      // every load in turn: 0.5 GB of slabs took 179 us, 2.8 TB/s)
       float t = 0.f;
-      for (int sp = 0; sp < j.nsplit; ++sp) t += s[(long)sp * j.stride + si];
+      int sp = 0;
+      for (; sp + 8 <= j.nsplit; sp += 8) {
+        float u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = s[(long)(sp + k) * j.stride + si];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += u[k];
+      }
+      for (; sp < j.nsplit; ++sp) t += s[(long)sp * j.stride + si];
       v = t;
     }
     dst[i] = accumulate ? dst[i] + v : v;
