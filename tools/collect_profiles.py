@@ -55,10 +55,10 @@ N, S = 2, 128
 # correction -- a wide coalesced read is tallied at half its bytes, MI355X_MICROARCH.md HBM section -- applies to wide reads only)
 kernels = {
     "conv2_fwd.b1": ("fprop_kernel<27, 1, 1, 1, 4, 1, 1, 2, 8, 2, 4, 32, true>", (1, 0), 6, True),
-    "conv2_dgrad.b1": ("fprop_kernel<27, 2, 2, 2, 2, 1, 2, 2, 2, 1, 4, 32, false>", (2, 0), 6, True),
+    "conv2_dgrad.b1": ("fprop_kernel<27, 2, 2, 2, 4, 1, 2, 2, 2, 2, 4, 32, false>", (2, 0), 6, True),
     "conv2_wgrad.b1": ("wgrad3_batched_kernel<1, 1, 2, 32>", (3, 0), 1, True),
     "conv2_wgrad.b2": ("wgrad3_batched_kernel<1, 1, 4, 16>", (3, 1), 1, True),
-    "stem_conv": ("stem_conv_kernel<true>", (7, 0), 1, False),
+    "stem_conv": ("stem_conv_kernel<2>", (7, 0), 1, False),
     "stem_wgrad": ("stem_wgrad_kernel", (8, 0), 1, False),
     "sgd": ("sgd_kernel", None, 1, True),
     "pack": ("pack_kernel", None, 1, False),
