@@ -97,7 +97,14 @@ int dispatch(const FpropArgs& a, hipStream_t s) {
     if (big == 1) return launch_cfg<27, PRO, EPI, 2, 4, 1, 2, 2, 2, 2, 4, 32>(a, s);
     return launch_cfg<27, PRO, EPI, 2, 2, 1, 2, 2, 2, 1, 4, 32>(a, s);
   }
-  if (a.W > 8) return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
+  if (a.W > 8) {
+    // r03: the 128 x 64 tile as eight one-tile waves (4 x 2) instead of 2 x 2 x 2 waves with two tiles each and an in-block K-split: no
+    // in-block reduction, and slice sum and epilogue run on all eight waves instead of four (9.5k + 4.7k of the launch's 66k cycles).
+    // conv2 data gradient at 2 x 16^3: 0.407 -> 0.370 ms per step (twelve launches).  MMNN_DGRAD16=0: the r02 shape.
+    static const int alt = [] { const char* e = getenv("MMNN_DGRAD16"); return e ? atoi(e) : 1; }();
+    if (alt == 1) return launch_cfg<27, PRO, EPI, 4, 2, 1, 1, 1, 4, 1, 4, 16>(a, s);
+    return launch_cfg<27, PRO, EPI, 2, 2, 2, 2, 1, 4, 1, 4, 16>(a, s);
+  }
   if (a.W > 4) return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 1, 4, 8>(a, s);
   return launch_cfg<27, PRO, EPI, 4, 1, 2, 1, 1, 4, 2, 4, 4>(a, s);
   }
