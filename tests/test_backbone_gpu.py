@@ -16,6 +16,8 @@ CASES = [
     (1, (6, 12, 24, 16), (64, 64, 64), 2),
     (2, (2, 2, 2), (40, 36, 44), 3),        # ragged, non power-of-two extents; odd remainders in every pool
     (2, (6, 12, 4), (64, 64, 64), 1),       # TinyDensenet layout, single sample
+    (3, (2, 2), (40, 44, 48), 2),           # stem kernels are instantiated per input-channel count (csrc/stem.hip): odd count, no channel pairing
+    (4, (2, 2), (36, 40, 44), 2),           # four channels: two LDS buffers of the conv0 forward at the 160 KB limit
 ]
 
 
