@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const GradJob* jobs, floa
   float* dst = grad + j.dst_off;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < j.count; i += (long)gridDim.x * 256) {
     float v;
+    long di = i;                              // destination index (kind 1 walks the SOURCE order: see below)
     if (j.kind == 3) {
       const double* s = static_cast<const double*>(j.src);
       double t = 0.0;
@@ -216,9 +217,14 @@ __global__ void __launch_bounds__(256) finalize_kernel(const GradJob* jobs, floa
       if (j.kind == 0) {
         si = i;
       } else if (j.kind == 1) {             // dst[m][c][tap] <- slab[tap][m][c]
-        const int tap = (int)(i % 27);
-        const long mc = i / 27;
-        si = (long)tap * j.M * j.C + mc;
+        // threads follow the slabs' order (tap-major, (m, c) contiguous): the nsplit reads of an element are the 0.5 GB this kernel
+        // moves and are now coalesced; the one write per element is the strided side (r03: in destination order a wave's 64 reads
+        // touched 27 different lines, 12 useful bytes each)
+        const long mc_n = (long)j.M * j.C;
+        const int tap = (int)(i / mc_n);
+        const long mc = i - (long)tap * mc_n;
+        si = i;
+        di = mc * 27 + tap;
       } else {                              // dst[m][c][tap343] <- slab[c][m][352]
         const int tap = (int)(i % 343);
         const long mc = i / 343;
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const GradJob* jobs, floa
       for (; sp < j.nsplit; ++sp) t += s[(long)sp * j.stride + si];
       v = t;
     }
-    dst[i] = accumulate ? dst[i] + v : v;
+    dst[di] = accumulate ? dst[di] + v : v;
   }
 }
 
