@@ -97,6 +97,39 @@ __global__ void __launch_bounds__(256) consumer_bwd_kernel(const ConsumerBwdArgs
   float* gc = a.g + (long)n * a.g_ns + (long)c * V;
   const float* dyc = a.dy + ((long)n * a.C + c) * (a.mode == 0 ? V : Do * Ho * Wo);
   float s0 = 0.f, s1 = 0.f;
+  if (a.mode == 1 && (a.W & 3) == 0 && ((((uintptr_t)xc | (uintptr_t)gc) & 15) == 0) && (Wo & 1) == 0 &&
+      (long)V * (a.W >> 2) < (4l << 32) && (long)a.D * a.H * a.H < (1l << 32)) {
+    // four consecutive voxels of a row per thread (r03): 16-byte accesses, and ONE (row, quad) decomposition by multiply-high per four
+    // elements -- per element the run-time divisions by W and H were ~60 vector instructions, and the 16.8 M elements of block 1's
+    // transition made this an ALU-bound kernel (4 launches, 98 us per step).  Per-row sums in the same order as the scalar loop would
+    // give them is not required: the totals go into fp64 atomics.
+    const int wq_n = a.W >> 2, rows = a.D * a.H, items = rows * wq_n;
+    const unsigned mg_q = wq_n > 1 ? (unsigned)((0x100000000ull + wq_n - 1) / wq_n) : 0u;      // exact for item * wq_n < 2^32
+    const unsigned mg_h = a.H > 1 ? (unsigned)((0x100000000ull + a.H - 1) / a.H) : 0u;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+      const int row = mg_q ? (int)__umulhi((unsigned)it, mg_q) : it;
+      const int w = (it - row * wq_n) << 2;
+      const int d = mg_h ? (int)__umulhi((unsigned)row, mg_h) : row;
+      const int h = row - d * a.H;
+      const int v = row * a.W + w;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xc + v);
+      const int pw = w >> 1, ph = h >> 1, pd = d >> 1;
+      float dy0 = 0.f, dy1 = 0.f;
+      if (pw < Wo && ph < Ho && pd < Do) {           // pw even, Wo even: pw + 1 < Wo as well
+        const float* q = dyc + ((long)pd * Ho + ph) * Wo + pw;
+        dy0 = 0.125f * q[0]; dy1 = 0.125f * q[1];
+      }
+      f32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(ca, x[e], cb) > 0.f ? (e < 2 ? dy0 : dy1) : 0.f;
+        g[e] = gam * z;
+        s0 += z;
+        s1 += z * (x[e] - mu) * rs;
+      }
+      *reinterpret_cast<f32x4*>(gc + v) = g;
+    }
+  } else
   for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
     const float x = xc[v];
     float z;
@@ -126,7 +159,9 @@ int launch_consumer_bwd(const ConsumerBwdArgs& a, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.C > 0 && a.N <= 65535 && a.C <= 65535, "consumer_bwd: bad extent");
   MMNN_REQUIRE(a.mode == 0 || a.mode == 1, "consumer_bwd: bad mode");
   const int V = a.D * a.H * a.W;
-  int gx = cdiv(V, 1024);
+  // every block starts with the coefficient chain of its channel (statistics loads + fp64 arithmetic, ~3 us): few, long blocks -- 8192
+  // voxels each, eight 16-byte items per thread (r03: 1024 voxels per block meant 16 384 blocks and eight rounds of that chain at 32^3)
+  int gx = cdiv(V, 8192);
   if (gx > 64) gx = 64;
   MMNN_LAUNCH(consumer_bwd_kernel, dim3(gx, a.C, a.N), dim3(256), 0, stream, a);
   MMNN_HIP(hipGetLastError());
