@@ -398,6 +398,35 @@ def test_cox_fractional_durations_not_truncated():
         assert abs(CoxPH(h[:, 0], ev[:, 0].to(DEV), du[:, 0].to(DEV), intended_order=True).item() - ref.item()) < 1e-5 * abs(ref.item())
 
 
+def test_cox_edge_cases_vs_oracle():
+    """Edges of the Cox kernel against the fp64 oracle: a batch above 1024 patients (sort scratch in global memory instead of LDS,
+    csrc/tail.hip), a single patient, and a weight sum of zero (the reference's 0 / 0 = NaN must come through, not an exception)."""
+    from mmnn_sts_amd.losses.GradientBlender import GradientBlender
+    from mmnn_sts_amd.losses.losses import CoxPH
+    from mmnn_sts_amd.utils.utils import surv_criterion
+    for n in (1, 1024, 1025, 1500):
+        p = torch.from_numpy(synth.uniform(f"coxe/p{n}", (3, n, 2))).double().requires_grad_(True)
+        ev = torch.from_numpy((synth.uniform(f"coxe/e{n}", (n, 2)) > -0.3).astype(np.int64))
+        ev[0] = 1
+        du = torch.from_numpy((1 + np.floor((synth.uniform(f"coxe/d{n}", (n, 2)) * .5 + .5) * 2998)).astype(np.int64))
+        b = R.Blender()
+        b.weights = torch.tensor([0.5, 0.3, 0.2], dtype=torch.float64)
+        loss, _ = b.compute_loss(p, ev, du)
+        loss.backward()
+        pg = p.detach().float().to(DEV).requires_grad_(True)
+        gb = GradientBlender(CoxPH, survival=True, surv_criterion=surv_criterion)
+        gb.weights = torch.tensor([0.5, 0.3, 0.2], device=DEV)
+        lg, _ = gb.computeLoss(pg, ev.to(DEV), du.to(DEV))
+        lg.backward()
+        # n = 1: the loss is log(1 + eps) = 1e-7 (1.19e-7 in float32) and the gradient 0 -- absolute floors for that case
+        assert abs(lg.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-6, n
+        assert np.abs(pg.grad.cpu().numpy() - p.grad.numpy()).max() < 1e-4 * np.abs(p.grad.numpy()).max() + 1e-7, n
+    h = torch.tensor([.3, -.2, .1, .4])
+    ref = R.CoxPH(h.double(), torch.tensor([1, 0, 1, 1]), torch.zeros(4, dtype=torch.int64))
+    got = CoxPH(h.to(DEV), torch.tensor([1, 0, 1, 1], device=DEV), torch.zeros(4, dtype=torch.int64, device=DEV))
+    assert torch.isnan(ref) and torch.isnan(got)
+
+
 @pytest.mark.parametrize("red", ["sum", "mean"])
 def test_classification_bce_and_blender_golden(red):
     """BASELINE configs[0] loss path on the device: pos-weighted BCE-with-logits kernel, `criterion`, and the blender's
