@@ -1,0 +1,243 @@
+// Dense-layer conv2 forward (models/densenet.py:80-85: ReLU(BN(t1)) -> 3x3x3 convolution to `growth` = 32 new channels -> channel dropout,
+// + the batch statistics of the new channels for their consumers) for extents wider than 16 voxels, on the bf16 matrix pipe with fp32 accuracy:
+// every fp32 operand is split into three bf16 pieces (x = hi + mid + lo, round to nearest at each step: 24 mantissa bits) and a product
+// becomes six v_mfma_f32_32x32x16_bf16 (mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi) into one fp32 accumulator.  Measured against fp64
+// (tools/microbench/bf16x3_gemm.hip, conv3_bf16x3.hip): 4.5e-7 rms -- the fp32 matrix instruction's own error is 1.0e-6 -- at 16x the
+// rate per instruction cycle; and the bf16 instruction leaves the vector ALU free beside it, which v_mfma_f32_32x32x2_f32 does not
+// (profiles/r03_microbench_mfma_acc_file.txt).  Same arguments, same results to fp32 rounding and the same statistics protocol as
+// fprop_kernel<27, PRO_BNRELU, EPI_STORE_STATS> (fprop.hpp), which stays the kernel for every other shape.
+//   MFMA mapping: i = output channel (32), j = voxel (32 consecutive w), k = input channel (16 per instruction); a tap is a row offset.
+//   Workgroup: 4 waves, a 2 x 4 x 32 voxel tile.  In-block K-split over the taps: every wave multiplies all eight 32-voxel rows with taps
+//   wv, wv + 4, ... (a weight operand serves 48 MFMAs, no two waves load the same weights); the four partial tiles are summed through LDS.
+//   LDS: the halo tile of a 16-channel chunk as three bf16 planes [piece][channel half][halo voxel] of 16-byte entries, two buffers: chunk
+//   ch + 1 is loaded at the head of chunk ch's tap loop, BN + ReLU + split between its MFMAs, written to the other buffer; one barrier per chunk.
+#include <stdlib.h>
+
+#include "fprop.hpp"
+
+namespace mmnn {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+namespace c3b {
+constexpr int TD = 2, TH = 4, TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, KC = 16, NT = 7;
+constexpr int ITEMS = (2 * HV + 255) / 256;
+constexpr int MAXC = 256;
+constexpr size_t OPER_BYTES = (size_t)2 * 6 * HV * 16;                            // two buffers of [3][2][HV] 16-byte entries
+constexpr size_t SMEM = OPER_BYTES + sizeof(float) * (2 * MAXC + 2 * 4 * 32 + 32);   // + BN coefficients, statistics scratch, dropout scales
+static_assert(ITEMS <= NT, "one staging item per tap slot");
+static_assert(4 * 8 * 16 * 64 * sizeof(float) <= OPER_BYTES, "the partial tiles are summed in the operand buffers");
+static_assert(SMEM <= 160 * 1024, "LDS");
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+__device__ __forceinline__ uint32_t pack2(__bf16 lo, __bf16 hi) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+}  // namespace c3b
+
+__global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a) {
+  using namespace c3b;
+  extern __shared__ uint4 xs128[];                          // [2][3][2][HV]
+  float* const coef = reinterpret_cast<float*>(reinterpret_cast<char*>(xs128) + OPER_BYTES);   // [2][MAXC]: a_c, b_c
+  float* const sred = coef + 2 * MAXC;                      // [2][4][32]
+  float* const dsc = sred + 2 * 4 * 32;                     // [32] dropout scale of the output channels
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = tid & 1;
+  const int D = a.D, H = a.H, W = a.W, V = D * H * W, Cin = a.Cin, nchunk = Cin / KC;
+  const int twn = (W + TW - 1) / TW, thn = (H + TH - 1) / TH, tdn = (D + TD - 1) / TD;
+  int b = blockIdx.x;
+  const int w0 = (b % twn) * TW; b /= twn;
+  const int h0 = (b % thn) * TH; b /= thn;
+  const int d0 = (b % tdn) * TD;
+  const int n = b / tdn;
+  const float* __restrict__ xin = a.in0 + (long)n * a.in0_ns + (long)a.in0_coff * V;
+  const float* __restrict__ wgt = a.w;
+  for (int c = tid; c < Cin; c += 256) {
+    float ca_, cb_, mu, rs;
+    bn_fwd_coef(a.bn_in, c, ca_, cb_, mu, rs);
+    coef[c] = ca_; coef[MAXC + c] = cb_;
+  }
+  if (tid < 32) dsc[tid] = drop_scale(a.drop_out, n, tid);
+  f32x16_t acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  float xr[ITEMS][8], ca[8], cb[8];
+  auto item_pos = [&](int it, int& hv, int& o) -> bool {
+    const int item = tid + it * 256;
+    hv = item >> 1;
+    const int hd = hv / (HH * HW), hh = (hv / HW) % HH, hw = hv % HW;
+    const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+    o = (d * H + h) * W + w;
+    return item < 2 * HV && (unsigned)d < (unsigned)D && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+  };
+  auto issue = [&](int ch) {
+    const int c0 = ch * KC + 8 * g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = coef[c0 + e]; cb[e] = coef[MAXC + c0 + e]; }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      int hv, o;
+      const bool ok = item_pos(it, hv, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xr[it][e] = ok ? xin[(long)(c0 + e) * V + o] : 0.f;
+    }
+  };
+  auto commit_item = [&](int it, int buf) {
+    int hv, o;
+    const bool ok = item_pos(it, hv, o);
+    if (tid + it * 256 >= 2 * HV) return;
+    __bf16 ph[8], pm[8], pl[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(ok ? fmaxf(fmaf(ca[e], xr[it][e], cb[e]), 0.f) : 0.f, ph[e], pm[e], pl[e]);   // zero padding AFTER BN + ReLU
+    uint4* dst = xs128 + buf * (6 * HV);
+    dst[(0 * 2 + g) * HV + hv] = make_uint4(pack2(ph[0], ph[1]), pack2(ph[2], ph[3]), pack2(ph[4], ph[5]), pack2(ph[6], ph[7]));
+    dst[(1 * 2 + g) * HV + hv] = make_uint4(pack2(pm[0], pm[1]), pack2(pm[2], pm[3]), pack2(pm[4], pm[5]), pack2(pm[6], pm[7]));
+    dst[(2 * 2 + g) * HV + hv] = make_uint4(pack2(pl[0], pl[1]), pack2(pl[2], pl[3]), pack2(pl[4], pl[5]), pack2(pl[6], pl[7]));
+  };
+  // weights w[(c * 27 + tap) * w_ld + m] (fp32 panel of the library): lane = (row m, channel half); ring slot ti holds tap wv + 4 ti of the
+  // chunk ahead as eight raw fp32 values, split into the three operand pieces where they are used
+  float wr[NT][8];
+  auto load_w = [&](int ti, int ch) {
+    const int tap = wv + 4 * ti;
+    if (tap < 27 && ch < nchunk) {
+      const int c0 = ch * KC + 8 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wr[ti][e] = wgt[((long)(c0 + e) * 27 + tap) * a.w_ld + (lane & 31)];
+    }
+  };
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) load_w(ti, 0);
+  __syncthreads();                                          // coefficients
+  issue(0);
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) commit_item(it, 0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cur = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    if (more) issue(ch + 1);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int tap = wv + 4 * ti;
+      if (tap < 27) {
+        const int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+        __bf16 ph[8], pm[8], pl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(wr[ti][e], ph[e], pm[e], pl[e]);
+        bf16x8_t aw[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { aw[0][e] = ph[e]; aw[1][e] = pm[e]; aw[2][e] = pl[e]; }
+        load_w(ti, ch + 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int hv = ((t / 4 + td) * HH + (t % 4 + th)) * HW + ((lane & 31) + tw);
+          bf16x8_t bb[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bb[p] = as_bf16x8(xs128[cur * (6 * HV) + (p * 2 + (lane >> 5)) * HV + hv]);
+          // smallest products first: their sum is formed before it meets the large one
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[1], bb[1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[0], bb[2], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[2], bb[0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[0], bb[1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[1], bb[0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[0], bb[0], acc[t], 0, 0, 0);
+        }
+      }
+      if (more) commit_item(ti, cur ^ 1);
+    }
+    __syncthreads();
+  }
+  // sum the four waves' partial tiles (fixed order) through LDS; wave wv finishes rows 2 wv and 2 wv + 1 of the tile.
+  // register q of lane l: output channel 8 * (q / 4) + 4 * (l / 32) + q % 4, voxel column l % 32
+  float* red = reinterpret_cast<float*>(xs128);            // [wave][row][q][lane]
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[((wv * 8 + t) * 16 + q) * 64 + lane] = acc[t][q];
+  __syncthreads();
+  float* __restrict__ outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
+  const bool want_sums = a.st_out.sum != nullptr;
+  float s0[16], s1[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = 2 * wv + tt;
+    const int d = d0 + t / 4, h = h0 + t % 4, w = w0 + (lane & 31);
+    const bool ok = d < D && h < H && w < W;
+    const int o = (d * H + h) * W + w;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) v += red[((w2 * 8 + t) * 16 + q) * 64 + lane];
+      const int m = 8 * (q / 4) + 4 * (lane >> 5) + q % 4;
+      v *= dsc[m];
+      if (ok) {
+        outn[(long)m * V + o] = v;
+        s0[q] += v;
+        s1[q] += v * v;
+      }
+    }
+  }
+  if (want_sums) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float t0 = s0[q], t1 = s1[q];
+      t0 += swz_xor<16>(t0); t1 += swz_xor<16>(t1);
+      t0 += swz_xor<8>(t0);  t1 += swz_xor<8>(t1);
+      t0 += swz_xor<4>(t0);  t1 += swz_xor<4>(t1);
+      t0 += swz_xor<2>(t0);  t1 += swz_xor<2>(t1);
+      t0 += swz_xor<1>(t0);  t1 += swz_xor<1>(t1);
+      if ((lane & 31) == 0) {
+        const int m = 8 * (q / 4) + 4 * (lane >> 5) + q % 4;
+        sred[wv * 32 + m] = t0;
+        sred[4 * 32 + wv * 32 + m] = t1;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int rep = blockIdx.x & ((a.nrep > 0 ? a.nrep : NREP) - 1);
+      double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) { v0 += (double)sred[w2 * 32 + tid]; v1 += (double)sred[4 * 32 + w2 * 32 + tid]; }
+      atomicAdd(a.st_out.sum + (long)rep * a.st_out.stride + a.st_out.off + tid, v0);
+      atomicAdd(a.st_out.sq + (long)rep * a.st_out.stride + a.st_out.off + tid, v1);
+    }
+  }
+}
+
+// Shapes this kernel takes (everything else stays on fprop_kernel): 32 output channels, input channels in chunks of 16, rows wider than
+// 16 voxels.  MMNN_BF16X3=0 switches it off (A/B runs, debugging).
+bool conv3_fwd_bf16x3_eligible(const FpropArgs& a) {
+  static const bool off = [] { const char* e = getenv("MMNN_BF16X3"); return e && e[0] == '0'; }();
+  return !off && a.M == 32 && a.Cin % c3b::KC == 0 && a.Cin >= c3b::KC && a.Cin <= c3b::MAXC && a.W > 16;
+}
+
+int launch_conv3_fwd_bf16x3(const FpropArgs& a, hipStream_t stream) {
+  using namespace c3b;
+  MMNN_REQUIRE(conv3_fwd_bf16x3_eligible(a), "conv3 bf16x3: shape not handled (M=%d, Cin=%d, W=%d)", a.M, a.Cin, a.W);
+  MMNN_REQUIRE(a.drop_in.p <= 0.f, "conv3 bf16x3: no input dropout on this path");
+  const long tiles = (long)a.N * cdiv(a.D, TD) * cdiv(a.H, TH) * cdiv(a.W, TW);
+  MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31), "conv3 bf16x3: grid out of range");
+  MMNN_REQUIRE((long)(a.Cin + 1) * a.D * a.H * a.W < (1l << 31), "conv3 bf16x3: volume too large for 32-bit element offsets");
+  static bool configured[MAX_DEVICES] = {false};
+  bool& conf = configured[current_device_slot()];
+  if (!conf) {
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+    conf = true;
+  }
+  MMNN_LAUNCH(conv3_fwd_bf16x3_kernel, dim3((unsigned)tiles), dim3(256), SMEM, stream, a);
+  MMNN_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mmnn

@@ -22,6 +22,10 @@ extern template int dispatch<1, PRO_GRAD, EPI_STORE>(const FpropArgs&, hipStream
 extern template int dispatch<27, PRO_BNRELU, EPI_STORE_STATS>(const FpropArgs&, hipStream_t);
 extern template int dispatch<27, PRO_GRAD, EPI_MASK_STORE>(const FpropArgs&, hipStream_t);
 
+// conv3_bf16x3.hip: the dense-layer conv2 forward on three-piece bf16 MFMAs (wide extents, 32 output channels)
+bool conv3_fwd_bf16x3_eligible(const FpropArgs& a);
+int launch_conv3_fwd_bf16x3(const FpropArgs& a, hipStream_t stream);
+
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "fprop: non-positive extent");
   MMNN_REQUIRE((long)a.D * a.H * a.W < (1l << 30), "fprop: volume too large for 32-bit voxel indices");
@@ -29,6 +33,7 @@ int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t str
   MMNN_REQUIRE((long)(a.M + 128) * a.D * a.H * a.W < (1l << 31), "fprop: output rows x volume too large for 32-bit element offsets");
   MMNN_REQUIRE(pro != PRO_GRAD || a.in1, "fprop: PRO_GRAD needs the normalised tensor (in1)");
   MMNN_REQUIRE((epi != EPI_MASK_STORE && epi != EPI_MASK_ACCUM) || (a.ex && a.dgamma && a.dbeta), "fprop: mask epilogue operands missing");
+  if (taps == 27 && pro == PRO_BNRELU && epi == EPI_STORE_STATS && conv3_fwd_bf16x3_eligible(a)) return launch_conv3_fwd_bf16x3(a, stream);
 #define MMNN_CASE(T, P, E) \
   if (taps == T && pro == P && epi == E) return dispatch<T, P, E>(a, stream);
   MMNN_CASE(1, PRO_BNRELU, EPI_STORE_STATS)    // dense-layer conv1 forward
