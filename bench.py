@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_VOLUME = 268.9          # fwd + bwd algorithmic FLOPs of one 2x128^3 volume
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
 N_CLIN = 32
 
 
@@ -165,13 +166,20 @@ def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
         tf = flop / (ms * 1e-3) / 1e12
         tbs = byts / (ms * 1e-3) / 1e12
         name = KCLASS[kind] + ("" if kind in (7, 8) else f".b{b + 1}")
+        # conv2 forward at extents wider than 16 voxels runs on the bf16 matrix pipe with three-piece operands (csrc/conv3_bf16x3.hip):
+        # six bf16 MFMA products per fp32 product, priced against the dense bf16 peak
+        bf16x3 = kind == 1 and ((size // 4) >> b) > 16 and os.environ.get("MMNN_BF16X3", "1") != "0"
+        peak_tf, pipe_mult = (PEAK_BF16_TFLOPS, 6.0) if bf16x3 else (PEAK_FP32_TFLOPS, 1.0)
         # which roof bounds the class: the one its algorithmic work takes longer to cross
-        hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > flop / (PEAK_FP32_TFLOPS * 1e12)
+        hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > pipe_mult * flop / (peak_tf * 1e12)
         row = {"class": name, "kernel": KDESC[kind] + ("" if kind in (7, 8) else f", dense block {b + 1}"), "launches": int(cnt),
                "ms_per_step": ms / steps, "avg_us": ms / cnt * 1e3, "flop_per_launch": flop / cnt, "bytes_per_launch": byts / cnt,
-               "bound": "hbm" if hbm_bound else "mfma", "mfma_tflops": tf, "mfma_frac": tf / PEAK_FP32_TFLOPS, "hbm_tbs": tbs,
+               "bound": "hbm" if hbm_bound else "mfma", "mfma_tflops": pipe_mult * tf, "mfma_frac": pipe_mult * tf / peak_tf, "hbm_tbs": tbs,
                "hbm_frac": tbs / HBM_ACHIEVABLE_TBS, "hbm_frac_of_spec": tbs / HBM_SPEC_TBS}
-        row["achieved"], row["peak"], row["unit"] = (tbs, HBM_ACHIEVABLE_TBS, "TB/s") if hbm_bound else (tf, PEAK_FP32_TFLOPS, "TFLOP/s")
+        if bf16x3:
+            row["pipe"] = "bf16, three pieces per fp32 operand: 6 MFMA products per fp32 product (mfma_tflops counts them; peak = dense bf16)"
+            row["fp32_equivalent_tflops"] = tf
+        row["achieved"], row["peak"], row["unit"] = (tbs, HBM_ACHIEVABLE_TBS, "TB/s") if hbm_bound else (pipe_mult * tf, peak_tf, "TFLOP/s")
         row["frac"] = row["achieved"] / row["peak"]
         if max(row["mfma_frac"], row["hbm_frac"]) < 0.15:
             row["limiter"] = "latency"      # neither roof is near: a chain of memory round trips (the 8^3 / 4^3 layers)
@@ -431,6 +439,9 @@ def main():
             "metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup, "init_steps": init_steps, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 tensors and fp32 accumulation throughout; the dense-layer conv2 forward at extents wider than 16 voxels multiplies "
+                          "three-piece bf16 splits of its fp32 operands (6 bf16 MFMA products per fp32 product, error at the fp32 MFMA's own level; "
+                          "every parity test runs at unchanged tolerance; MMNN_BF16X3=0 restores the fp32 MFMA kernel)",
             "per_gpu": value / world,
             "config": {"workload": workload, "micro_batch": a.micro_batch, "global_batch": a.micro_batch * world,
                        "volume": [in_ch, a.size, a.size, a.size], "tabular": 0 if unimodal else N_CLIN, "parallelism": f"dp{world}",
