@@ -308,6 +308,8 @@ def run_gradcam256(a, dev, L):
                        "volume": [2, s, s, s], "tabular": N_CLIN, "batch": 1},
             "roofline": {"bound": "mfma", "kernel": "eval-mode backbone forward (all convolutions)", "achieved": flops / (fwd * 1e-3) / 1e12,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": flops / (fwd * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+                         "note": "fp32-equivalent FLOPs of the whole eval forward against the fp32 MFMA peak; the conv2 layers of the 64^3 and 32^3 blocks run "
+                                 "on the bf16 pipe with three-piece operands (csrc/conv3_bf16x3.hip), so this is a throughput figure, not one kernel's roofline",
                          "backbone_forward_ms": fwd, "gradcam_tail_ms": dt * 1e3 - fwd,
                          "upsample_bytes_written": out_bytes, "clock_mhz": measure_clock(L, dev)},
             "reference_cpu_s_per_patient": "23-36 (BASELINE.md, reference on 8 vCPU)"}
