@@ -168,7 +168,8 @@ def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
         name = KCLASS[kind] + ("" if kind in (7, 8) else f".b{b + 1}")
         # conv2 forward at extents wider than 16 voxels runs on the bf16 matrix pipe with three-piece operands (csrc/conv3_bf16x3.hip):
         # six bf16 MFMA products per fp32 product, priced against the dense bf16 peak
-        bf16x3 = kind == 1 and ((size // 4) >> b) > 16 and os.environ.get("MMNN_BF16X3", "1") != "0"
+        bf16x3_mode = os.environ.get("MMNN_BF16X3", "32")
+        bf16x3 = kind == 1 and bf16x3_mode != "0" and ((size // 4) >> b) > (8 if bf16x3_mode == "16" else 16)
         peak_tf, pipe_mult = (PEAK_BF16_TFLOPS, 6.0) if bf16x3 else (PEAK_FP32_TFLOPS, 1.0)
         # which roof bounds the class: the one its algorithmic work takes longer to cross
         hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > pipe_mult * flop / (peak_tf * 1e12)

@@ -21,14 +21,21 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 namespace c3b {
-constexpr int TD = 2, TH = 4, TW = 32, HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, KC = 16, NT = 7;
-constexpr int ITEMS = (2 * HV + 255) / 256;
-constexpr int MAXC = 256;
-constexpr size_t OPER_BYTES = (size_t)2 * 6 * HV * 16;                            // two buffers of [3][2][HV] 16-byte entries
-constexpr size_t SMEM = OPER_BYTES + sizeof(float) * (2 * MAXC + 2 * 4 * 32 + 32);   // + BN coefficients, statistics scratch, dropout scales
-static_assert(ITEMS <= NT, "one staging item per tap slot");
-static_assert(4 * 8 * 16 * 64 * sizeof(float) <= OPER_BYTES, "the partial tiles are summed in the operand buffers");
-static_assert(SMEM <= 160 * 1024, "LDS");
+constexpr int KC = 16, NT = 7, MAXC = 256;
+// Tile geometry: TD x TH x TW voxels = ROWS rows of 32 voxels (voxel v = 32 row + column: w = v % TW, h = (v / TW) % TH, d = v / (TW TH)).
+//   <2, 4, 32>: 256 voxels, extents wider than 16 (one workgroup per CU at 2 x 32^3).
+//   <1, 2, 16>: 32 voxels (one row of two h-lines), extents of 9..16: 256 workgroups at 2 x 16^3 (opt-in, measured slower: see below).
+template <int TD, int TH, int TW>
+struct Geo {
+  static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW, ROWS = TD * TH * TW / 32;
+  static constexpr int ITEMS = (2 * HV + 255) / 256;
+  static constexpr size_t OPER_BYTES = (size_t)2 * 6 * HV * 16;                            // two buffers of [3][2][HV] 16-byte entries
+  static constexpr size_t SMEM = OPER_BYTES + sizeof(float) * (2 * MAXC + 2 * 4 * 32 + 32);   // + BN coefficients, statistics scratch, dropout scales
+  static_assert(TD * TH * TW % 32 == 0 && (TW == 32 || TW == 16), "rows of 32 voxels");
+  static_assert(ITEMS <= NT, "one staging item per tap slot");
+  static_assert(4 * ROWS * 16 * 64 * sizeof(float) <= OPER_BYTES, "the partial tiles are summed in the operand buffers");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+};
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -42,8 +49,12 @@ __device__ __forceinline__ uint32_t pack2(__bf16 lo, __bf16 hi) {
 __device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 }  // namespace c3b
 
+template <int TD, int TH, int TW>
 __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a) {
   using namespace c3b;
+  using G = Geo<TD, TH, TW>;
+  constexpr int HH = G::HH, HW = G::HW, HV = G::HV, ROWS = G::ROWS, ITEMS = G::ITEMS;
+  constexpr size_t OPER_BYTES = G::OPER_BYTES;
   extern __shared__ uint4 xs128[];                          // [2][3][2][HV]
   float* const coef = reinterpret_cast<float*>(reinterpret_cast<char*>(xs128) + OPER_BYTES);   // [2][MAXC]: a_c, b_c
   float* const sred = coef + 2 * MAXC;                      // [2][4][32]
@@ -64,9 +75,9 @@ __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a
     coef[c] = ca_; coef[MAXC + c] = cb_;
   }
   if (tid < 32) dsc[tid] = drop_scale(a.drop_out, n, tid);
-  f32x16_t acc[8];
+  f32x16_t acc[ROWS];
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < ROWS; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
   float xr[ITEMS][8], ca[8], cb[8];
@@ -137,8 +148,9 @@ __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a
         for (int e = 0; e < 8; ++e) { aw[0][e] = ph[e]; aw[1][e] = pm[e]; aw[2][e] = pl[e]; }
         load_w(ti, ch + 1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int hv = ((t / 4 + td) * HH + (t % 4 + th)) * HW + ((lane & 31) + tw);
+        for (int t = 0; t < ROWS; ++t) {
+          const int v = t * 32 + (lane & 31);
+          const int hv = ((v / (TW * TH) + td) * HH + ((v / TW) % TH + th)) * HW + (v % TW + tw);
           bf16x8_t bb[3];
 #pragma unroll
           for (int p = 0; p < 3; ++p) bb[p] = as_bf16x8(xs128[cur * (6 * HV) + (p * 2 + (lane >> 5)) * HV + hv]);
@@ -151,17 +163,17 @@ __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[0], bb[0], acc[t], 0, 0, 0);
         }
       }
-      if (more) commit_item(ti, cur ^ 1);
+      if (more && ti < ITEMS) commit_item(ti, cur ^ 1);
     }
     __syncthreads();
   }
-  // sum the four waves' partial tiles (fixed order) through LDS; wave wv finishes rows 2 wv and 2 wv + 1 of the tile.
+  // sum the four waves' partial tiles (fixed order) through LDS; wave wv finishes rows wv, wv + 4, ... of the tile.
   // register q of lane l: output channel 8 * (q / 4) + 4 * (l / 32) + q % 4, voxel column l % 32
   float* red = reinterpret_cast<float*>(xs128);            // [wave][row][q][lane]
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < ROWS; ++t)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) red[((wv * 8 + t) * 16 + q) * 64 + lane] = acc[t][q];
+    for (int q = 0; q < 16; ++q) red[((wv * ROWS + t) * 16 + q) * 64 + lane] = acc[t][q];
   __syncthreads();
   float* __restrict__ outn = a.out + (long)n * a.out_ns + (long)a.out_coff * V;
   const bool want_sums = a.st_out.sum != nullptr;
@@ -169,22 +181,24 @@ __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a
 #pragma unroll
   for (int q = 0; q < 16; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int t = 2 * wv + tt;
-    const int d = d0 + t / 4, h = h0 + t % 4, w = w0 + (lane & 31);
+  for (int tt = 0; tt < (ROWS + 3) / 4; ++tt) {
+    const int t = wv + 4 * tt;
+    if (t >= ROWS) break;
+    const int v = t * 32 + (lane & 31);
+    const int d = d0 + v / (TW * TH), h = h0 + (v / TW) % TH, w = w0 + v % TW;
     const bool ok = d < D && h < H && w < W;
     const int o = (d * H + h) * W + w;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      float v = 0.f;
+      float val = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) v += red[((w2 * 8 + t) * 16 + q) * 64 + lane];
+      for (int w2 = 0; w2 < 4; ++w2) val += red[((w2 * ROWS + t) * 16 + q) * 64 + lane];
       const int m = 8 * (q / 4) + 4 * (lane >> 5) + q % 4;
-      v *= dsc[m];
+      val *= dsc[m];
       if (ok) {
-        outn[(long)m * V + o] = v;
-        s0[q] += v;
-        s1[q] += v * v;
+        outn[(long)m * V + o] = val;
+        s0[q] += val;
+        s1[q] += val * val;
       }
     }
   }
@@ -216,28 +230,36 @@ __global__ void __launch_bounds__(256) conv3_fwd_bf16x3_kernel(const FpropArgs a
 }
 
 // Shapes this kernel takes (everything else stays on fprop_kernel): 32 output channels, input channels in chunks of 16, rows wider than
-// 16 voxels.  MMNN_BF16X3=0 switches it off (A/B runs, debugging).
+// 16 voxels.  MMNN_BF16X3=0 switches it off (A/B runs, debugging).  MMNN_BF16X3=16 also sends the 9..16-voxel extents here (the <1, 2, 16>
+// tile): parity-green but SLOWER than fprop_kernel at 2 x 16^3 (40.6 vs 28.2 us per launch, profiles/r03_ab_experiments.txt) -- 256 workgroups
+// of 32 voxels each stage a 6.75x halo and read all 442 KB of weights; those layers need a cross-workgroup K-split instead.  Off by default.
 bool conv3_fwd_bf16x3_eligible(const FpropArgs& a) {
-  static const bool off = [] { const char* e = getenv("MMNN_BF16X3"); return e && e[0] == '0'; }();
-  return !off && a.M == 32 && a.Cin % c3b::KC == 0 && a.Cin >= c3b::KC && a.Cin <= c3b::MAXC && a.W > 16;
+  static const int mode = [] { const char* e = getenv("MMNN_BF16X3"); return e ? atoi(e) : 32; }();
+  return mode != 0 && a.M == 32 && a.Cin % c3b::KC == 0 && a.Cin >= c3b::KC && a.Cin <= c3b::MAXC && a.W > (mode == 16 ? 8 : 16);
 }
 
-int launch_conv3_fwd_bf16x3(const FpropArgs& a, hipStream_t stream) {
-  using namespace c3b;
-  MMNN_REQUIRE(conv3_fwd_bf16x3_eligible(a), "conv3 bf16x3: shape not handled (M=%d, Cin=%d, W=%d)", a.M, a.Cin, a.W);
-  MMNN_REQUIRE(a.drop_in.p <= 0.f, "conv3 bf16x3: no input dropout on this path");
+template <int TD, int TH, int TW>
+static int launch_geo(const FpropArgs& a, hipStream_t stream) {
+  using G = c3b::Geo<TD, TH, TW>;
   const long tiles = (long)a.N * cdiv(a.D, TD) * cdiv(a.H, TH) * cdiv(a.W, TW);
   MMNN_REQUIRE(tiles > 0 && tiles < (1l << 31), "conv3 bf16x3: grid out of range");
-  MMNN_REQUIRE((long)(a.Cin + 1) * a.D * a.H * a.W < (1l << 31), "conv3 bf16x3: volume too large for 32-bit element offsets");
   static bool configured[MAX_DEVICES] = {false};
   bool& conf = configured[current_device_slot()];
   if (!conf) {
-    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+    MMNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_bf16x3_kernel<TD, TH, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
     conf = true;
   }
-  MMNN_LAUNCH(conv3_fwd_bf16x3_kernel, dim3((unsigned)tiles), dim3(256), SMEM, stream, a);
+  MMNN_LAUNCH((conv3_fwd_bf16x3_kernel<TD, TH, TW>), dim3((unsigned)tiles), dim3(256), G::SMEM, stream, a);
   MMNN_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_conv3_fwd_bf16x3(const FpropArgs& a, hipStream_t stream) {
+  MMNN_REQUIRE(conv3_fwd_bf16x3_eligible(a), "conv3 bf16x3: shape not handled (M=%d, Cin=%d, W=%d)", a.M, a.Cin, a.W);
+  MMNN_REQUIRE(a.drop_in.p <= 0.f, "conv3 bf16x3: no input dropout on this path");
+  MMNN_REQUIRE((long)(a.Cin + 1) * a.D * a.H * a.W < (1l << 31), "conv3 bf16x3: volume too large for 32-bit element offsets");
+  if (a.W > 16) return launch_geo<2, 4, 32>(a, stream);
+  return launch_geo<1, 2, 16>(a, stream);
 }
 
 }  // namespace mmnn
