@@ -166,10 +166,12 @@ def kernel_roofline(L, plan, step, n, size, steps=4, in_ch=2):
         tf = flop / (ms * 1e-3) / 1e12
         tbs = byts / (ms * 1e-3) / 1e12
         name = KCLASS[kind] + ("" if kind in (7, 8) else f".b{b + 1}")
-        # conv2 forward at extents wider than 16 voxels runs on the bf16 matrix pipe with three-piece operands (csrc/conv3_bf16x3.hip):
+        # conv2 forward and data gradient at extents wider than 16 voxels run on the bf16 matrix pipe with three-piece operands (csrc/conv3_bf16x3.hip):
         # six bf16 MFMA products per fp32 product, priced against the dense bf16 peak
         bf16x3_mode = os.environ.get("MMNN_BF16X3", "32")
-        bf16x3 = kind == 1 and bf16x3_mode != "0" and ((size // 4) >> b) > (8 if bf16x3_mode == "16" else 16)
+        wide = ((size // 4) >> b) > 16
+        bf16x3 = bf16x3_mode != "0" and ((kind == 1 and (wide or (bf16x3_mode == "16" and ((size // 4) >> b) > 8)))
+                                         or (kind == 2 and wide and os.environ.get("MMNN_BF16X3_DGRAD", "1") != "0"))
         peak_tf, pipe_mult = (PEAK_BF16_TFLOPS, 6.0) if bf16x3 else (PEAK_FP32_TFLOPS, 1.0)
         # which roof bounds the class: the one its algorithmic work takes longer to cross
         hbm_bound = byts / (HBM_ACHIEVABLE_TBS * 1e12) > pipe_mult * flop / (peak_tf * 1e12)
@@ -442,8 +444,8 @@ def main():
             "metric": metric, "value": value, "unit": unit,
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup, "init_steps": init_steps, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 tensors and fp32 accumulation throughout; the dense-layer conv2 forward at extents wider than 16 voxels multiplies "
-                          "three-piece bf16 splits of its fp32 operands (6 bf16 MFMA products per fp32 product, error at the fp32 MFMA's own level; "
+            "dtype_note": "fp32 tensors and fp32 accumulation throughout; the dense-layer conv2 forward and data gradient at extents wider than 16 voxels multiply "
+                          "three-piece bf16 splits of their fp32 operands (6 bf16 MFMA products per fp32 product, error at the fp32 MFMA's own level; "
                           "every parity test runs at unchanged tolerance; MMNN_BF16X3=0 restores the fp32 MFMA kernel)",
             "per_gpu": value / world,
             "config": {"workload": workload, "micro_batch": a.micro_batch, "global_batch": a.micro_batch * world,

@@ -25,6 +25,8 @@ extern template int dispatch<27, PRO_GRAD, EPI_MASK_STORE>(const FpropArgs&, hip
 // conv3_bf16x3.hip: the dense-layer conv2 forward on three-piece bf16 MFMAs (wide extents, 32 output channels)
 bool conv3_fwd_bf16x3_eligible(const FpropArgs& a);
 int launch_conv3_fwd_bf16x3(const FpropArgs& a, hipStream_t stream);
+bool conv3_dgrad_bf16x3_eligible(const FpropArgs& a);
+int launch_conv3_dgrad_bf16x3(const FpropArgs& a, hipStream_t stream);
 
 int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t stream) {
   MMNN_REQUIRE(a.N > 0 && a.D > 0 && a.H > 0 && a.W > 0 && a.Cin > 0 && a.M > 0, "fprop: non-positive extent");
@@ -34,6 +36,7 @@ int launch_fprop(const FpropArgs& a, int taps, int pro, int epi, hipStream_t str
   MMNN_REQUIRE(pro != PRO_GRAD || a.in1, "fprop: PRO_GRAD needs the normalised tensor (in1)");
   MMNN_REQUIRE((epi != EPI_MASK_STORE && epi != EPI_MASK_ACCUM) || (a.ex && a.dgamma && a.dbeta), "fprop: mask epilogue operands missing");
   if (taps == 27 && pro == PRO_BNRELU && epi == EPI_STORE_STATS && conv3_fwd_bf16x3_eligible(a)) return launch_conv3_fwd_bf16x3(a, stream);
+  if (taps == 27 && pro == PRO_GRAD && epi == EPI_MASK_STORE && conv3_dgrad_bf16x3_eligible(a)) return launch_conv3_dgrad_bf16x3(a, stream);
 #define MMNN_CASE(T, P, E) \
   if (taps == T && pro == P && epi == E) return dispatch<T, P, E>(a, stream);
   MMNN_CASE(1, PRO_BNRELU, EPI_STORE_STATS)    // dense-layer conv1 forward
