@@ -291,3 +291,19 @@ def test_persistent_block_forward_dropout_streams_match():
     za, zb = (xa.abs().sum(dim=(2, 3, 4)) == 0), (xb.abs().sum(dim=(2, 3, 4)) == 0)
     assert torch.equal(za, zb) and 0 < int(za.sum()) < za.numel() // 2
     assert rel_err(oa.cpu().numpy(), ob.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["0", "16"])
+def test_bf16x3_switch_positions_keep_parity(mode):
+    """The suite runs with the default kernel selection (conv2 forward / data gradient of extents wider than 16 voxels on three-piece bf16
+    MFMAs, csrc/conv3_bf16x3.hip).  The switches are read once per process, so the other positions run in a fresh one: MMNN_BF16X3=0 (the
+    fp32-MFMA kernels for every extent) and MMNN_BF16X3=16 (the opt-in 16-voxel tile as well) must pass the same tile-matrix parity
+    (ragged W = 17 / 33 included) against the fp64 oracle at the same tolerances."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMNN_BF16X3=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "tile_matrix"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
